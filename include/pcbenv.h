@@ -1,0 +1,174 @@
+/*
+ * pcbenv.h -- C ABI of libpcbenv.so: batched PCB component-placement
+ * environments on MI355X (gfx950).  Plain C, plain pointers and sizes, no torch
+ * or C++ types.  Everything is asynchronous on the caller's HIP stream.
+ *
+ * What each entry point replaces in the reference (PBozmarov/RL-Environment-for-
+ * Component-Placement, paths relative to its root):
+ *
+ *   pcbenv_create          DummyPlacementEnv.__init__ + parameter validation
+ *                            environment/dummy_env_square.py:37-72
+ *                            environment/dummy_env_rectangular.py:152-251
+ *                            environment/dummy_env_rectangular_pin.py:396-641
+ *                            environment/dummy_env_rectangular_pin_spatial.py:396-607
+ *                          and the factory utils/agent/utils.py:317-418 (init_env/create_env)
+ *   pcbenv_load_instances  the tables generate_instances() draws at reset
+ *                            ..._spatial.py:960-989 (and :931-1212, :1408-1443)
+ *   pcbenv_reset           DummyPlacementEnv.reset   ..._spatial.py:1487-1549,
+ *                            ..._pin.py:1544-1597, ..._rectangular.py:310-351, ..._square.py:74-113
+ *   pcbenv_step            DummyPlacementEnv.step    ..._spatial.py:1551-1661,
+ *                            ..._pin.py:1599-1710, ..._rectangular.py:353-432, ..._square.py:115-153
+ *                          incl. validate_action, update_grid, place_component,
+ *                          compute_action_mask, compute_if_done, find_reward
+ *   action formats         utils/environment/env_wrappers.py:80-98, :184-199 (flat Discrete action)
+ *   pcbenv_sample_actions  the uniform-random valid-action policy
+ *                            agent/random/random_policy_square.py:11-23 (and siblings)
+ *
+ * Observations are written into caller-owned device buffers (pcbenv_buffers)
+ * and updated in place by the next call; the library owns only the handle, the
+ * compact per-environment state and the instance queue.  Invalid actions are
+ * data (a terminal transition), never an error.
+ */
+#ifndef PCBENV_H
+#define PCBENV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCBENV_ABI_VERSION 1
+
+/* status codes (every function returning int) */
+#define PCBENV_OK 0
+#define PCBENV_EINVAL (-1)  /* bad parameter: the reference raises ValueError here */
+#define PCBENV_ELIMIT (-2)  /* valid for the reference but beyond the HIP path's limits below */
+#define PCBENV_EHIP (-3)    /* a HIP runtime call failed (no device, out of memory, launch error) */
+#define PCBENV_ESTATE (-4)  /* call order: buffers not bound, no instance loaded, ... */
+
+/* limits of the HIP path */
+#define PCBENV_MAX_SIDE 128
+#define PCBENV_MAX_COMPONENTS 64
+#define PCBENV_MAX_PINS 256
+#define PCBENV_MAX_NETS 32
+#define PCBENV_MAX_PINS_PER_NET 16
+#define PCBENV_MAX_PINS_PER_COMPONENT 64
+#define PCBENV_MAX_BEAM_WIDTH 4
+
+enum pcbenv_kind {
+    PCBENV_SQUARE = 0,  /* environment/dummy_env_square.py */
+    PCBENV_RECT = 1,    /* environment/dummy_env_rectangular.py */
+    PCBENV_PIN = 2,     /* environment/dummy_env_rectangular_pin.py */
+    PCBENV_SPATIAL = 3  /* environment/dummy_env_rectangular_pin_spatial.py */
+};
+enum pcbenv_reward_type { PCBENV_REWARD_BEAM = 0, PCBENV_REWARD_CENTROID = 1, PCBENV_REWARD_BOTH = 2 };
+
+/* action encodings accepted by pcbenv_step / produced by pcbenv_sample_actions */
+enum pcbenv_action_format {
+    PCBENV_ACTION_TUPLE = 0, /* int32 [num_envs, 3] = (orientation, x, y); square reads (x, y) from columns 1, 2 */
+    PCBENV_ACTION_FLAT = 1   /* int32 [num_envs]: a = o*H*W + x*W + y (square: x*W + y) */
+};
+
+/* flags */
+#define PCBENV_FLAG_INCREMENTAL_OBS 1u /* grid / pin_grid: write only the cells a step changed (buffers must
+                                          not be modified by the caller between calls) */
+
+/* Constructor parameters: the reference constructors' arguments, same names. */
+typedef struct pcbenv_config {
+    int32_t kind;
+    int32_t height, width;
+    int32_t min_component_w, max_component_w, min_component_h, max_component_h;
+    int32_t max_num_components, min_num_components;
+    int32_t net_distribution, pin_spread;
+    int32_t min_num_nets, max_num_nets, max_num_pins_per_net, min_num_pins_per_net;
+    int32_t reward_type;       /* enum pcbenv_reward_type */
+    int32_t reward_beam_width;
+    int32_t component_n;       /* square env only */
+    double weight_wirelength, weight_num_intersections;
+    /* batch */
+    int32_t num_envs;          /* environments on this device (one handle per process / GPU) */
+    int32_t queue_depth;       /* instances queued per environment (>= 1) */
+    uint32_t flags;
+    int32_t reserved;
+} pcbenv_config;
+
+/* Observation tensors (device pointers, C-contiguous, leading dim num_envs).
+ * A null pointer means "do not produce this tensor".  Cell tensors are uint8
+ * (values 0/1, identical to the reference's float64 0.0/1.0); the small feature
+ * tensors are float64 with exactly the reference's values.
+ *   O  = 1 (square), 2 (rect), 4 (pin, spatial)      C = max_num_components
+ *   mp = max_component_h*max_component_w             N = max_num_nets
+ *   F  = 5 (rect, pin) or 5+mp (spatial)
+ *   R  = C*mp (pin) or C*mp+1 (spatial)              Wc = 1 (pin) or 2 (spatial)            */
+typedef struct pcbenv_buffers {
+    uint8_t *grid;                  /* [B, H, W]                                all kinds  */
+    uint8_t *action_mask;           /* [B, O, H, W] (square: [B, H, W])         all kinds  */
+    uint8_t *pin_grid;              /* [B, H, W, N+1]                           spatial    */
+    uint8_t *component_grid;        /* [B, C, mh, mw, N+1]; rows >= #components are 0   spatial */
+    double *all_components_feature; /* [B, C, F]                                rect/pin/spatial */
+    double *placement_mask;         /* [B, C]                                   rect/pin/spatial */
+    double *component_mask;         /* [B, C]                                   rect       */
+    double *all_pins_num_feature;   /* [B, R, 4] (pin: viewed as [B, C, mp, 4]) pin/spatial */
+    double *all_pins_cat_feature;   /* [B, R, Wc] (pin: [B, C, mp, 1])          pin/spatial */
+    double *reward;                 /* [B]   required                                       */
+    uint8_t *done;                  /* [B]   required                                       */
+    double *info;                   /* [B, 2] = (wirelength, num_intersections); NaN where the reference's
+                                       info dict is empty                       pin/spatial */
+} pcbenv_buffers;
+
+/* Instance wire format (host memory), one record of pcbenv_instance_stride() bytes:
+ *   int32 num_components, num_nets, num_pins, reserved                      (16 bytes)
+ *   max_num_components x { uint8 h, w; uint8 pad[6] }                       (8 bytes each)
+ *   max_total_pins     x { uint8 rel_x, rel_y, net, component; uint16 pin_id; uint16 pad }
+ * Pins are in the order of the reference's `self.pins` list (net-major);
+ * max_total_pins = min(max_num_pins_per_net*max_num_nets,
+ *                      max_num_components*max_component_h*max_component_w). */
+typedef struct pcbenv pcbenv;
+
+int pcbenv_abi_version(void);
+
+/* Validates like the reference constructors (PCBENV_EINVAL) and against the
+ * limits above (PCBENV_ELIMIT), selects `device`, allocates state + queue.
+ * On failure *out is NULL and pcbenv_last_error(NULL) holds the message. */
+int pcbenv_create(const pcbenv_config *cfg, int device, pcbenv **out);
+void pcbenv_destroy(pcbenv *env);
+const char *pcbenv_last_error(const pcbenv *env);
+
+/* Sizes a host needs to allocate tensors and instance tables. */
+int64_t pcbenv_instance_stride(const pcbenv_config *cfg);
+int32_t pcbenv_max_total_pins(const pcbenv_config *cfg);
+
+int pcbenv_bind_buffers(pcbenv *env, const pcbenv_buffers *buffers);
+
+/* Copies n packed instance records (host memory) into queue slot `slot`
+ * (0 <= slot < queue_depth) of environments env_ids[0..n) (env_ids == NULL:
+ * environments 0..n-1).  Synchronous with respect to `stream`. */
+int pcbenv_load_instances(pcbenv *env, const int32_t *env_ids, int32_t n, int32_t slot,
+                          const void *host_tables, void *stream);
+
+/* reset(): every environment whose mask byte is non-zero (mask_dev == NULL: all)
+ * takes the next instance of its queue (round robin over the slots) and
+ * rewrites its observations.  Never called implicitly by pcbenv_step. */
+int pcbenv_reset(pcbenv *env, const uint8_t *mask_dev, void *stream);
+
+/* step(): one transition of every environment with the given actions. */
+int pcbenv_step(pcbenv *env, const int32_t *actions_dev, int32_t action_format, void *stream);
+
+/* Uniform draw over the currently legal actions of every environment
+ * (counter-based generator keyed by (seed, first_env_index + env, step_index));
+ * environments without a legal action get action 0. */
+int pcbenv_sample_actions(pcbenv *env, int32_t *actions_dev, int32_t action_format, uint64_t seed,
+                          uint64_t first_env_index, uint64_t step_index, void *stream);
+
+/* Bit-packed legal-action mask of the current component, library-owned device
+ * memory: uint64 [B, 2, H, ceil(W/64)] (orientation 0/1; pin kinds: 2 = 0, 3 = 1;
+ * square: plane 0 only), bit y of word [b, o, x, y/64] = action_mask[b, o, x, y].
+ * Also the row stride between environments in bytes. */
+const uint64_t *pcbenv_mask_bits(const pcbenv *env, int64_t *env_stride_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCBENV_H */

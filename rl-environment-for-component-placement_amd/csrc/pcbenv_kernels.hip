@@ -1,0 +1,956 @@
+// pcbenv_kernels.hip -- CDNA4 (gfx950) kernels + C ABI of libpcbenv.so.
+//
+// One environment per workgroup, one wavefront (64 lanes) per workgroup.
+// The occupancy grid lives bit-packed (one row = WW 64-bit words) in a compact
+// per-environment state block in HBM that is staged through LDS; the legal
+// placement mask is OR-folds of row words (horizontal: shifts; vertical: LDS
+// neighbours); the observation tensors the policy consumes (uint8 cells) are a
+// pure coalesced 16-byte-per-lane write stream, which is what bounds the kernel.
+//
+// Reference behaviour restated (file:line in the reference repo; S = environment/
+// dummy_env_rectangular_pin_spatial.py, P = ..._pin.py, R = ..._rectangular.py,
+// Q = dummy_env_square.py): see the comment on each device function.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (one IEEE operation per
+// written operator; the only fused multiply-add is the explicit __fma_rn in norm2).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "pcbenv.h"
+
+typedef unsigned long long u64;
+
+#define WAVE 64
+#define HDR_BYTES 32
+
+// ----------------------------------------------------------------------------------------------
+// device-side parameter block (kernel argument, by value)
+// ----------------------------------------------------------------------------------------------
+struct DevParams {
+    int kind, H, W, WW, O, C, P, N, K, mp, mh, mw, F, pinRows, catW, B, Q;
+    int reward_type, beam_width, component_n;
+    unsigned flags;
+    double w_wl, w_int, max_wl, max_int, wl_norm, int_norm, area;
+    long long stateStride, instStride;
+    int offOcc, offVm, offComps, offPins;   // byte offsets inside a state block
+    int ldsHf, ldsCls, ldsSeg, ldsBytes;    // byte offsets of LDS scratch behind the state mirror
+    unsigned char *state, *queue;
+    pcbenv_buffers buf;
+    unsigned char *pending;                 // [B] 1 = routed reward still to be computed (beam / both)
+};
+
+// per-environment header at the start of a state block
+struct __attribute__((aligned(16))) EnvHdr {
+    short ncomp, nnets, npins, cur;  // cur = index of the current component, -1 = sentinel (all placed)
+    unsigned episode;                // completed resets
+    unsigned qcursor;                // next queue slot
+    unsigned loaded;                 // bit s set = queue slot s holds an instance
+    unsigned pad[3];
+};
+static_assert(sizeof(EnvHdr) == HDR_BYTES, "header size");
+
+// 8-byte records (state block and instance wire format share the pin layout up to abs_x/abs_y)
+struct CompRec { unsigned char h, w; signed char px, py; unsigned char pad[4]; };
+struct PinRec { unsigned char rel_x, rel_y; signed char abs_x, abs_y; unsigned char net, comp; unsigned short id; };
+#define PIN_ID_MASK 0x7FFF
+#define PIN_LOSER 0x8000  // pin env quirk Q1: a later pin of the same component shares this feature row
+
+// ----------------------------------------------------------------------------------------------
+// bit rows
+// ----------------------------------------------------------------------------------------------
+template <int WW> struct Row;
+template <> struct Row<1> {
+    u64 a;
+    __device__ static Row load(const u64 *p) { return Row{p[0]}; }
+    __device__ void store(u64 *p) const { p[0] = a; }
+    __device__ Row operator|(Row o) const { return Row{a | o.a}; }
+    __device__ Row shr(int k) const { return Row{k >= 64 ? 0ull : a >> k}; }
+    __device__ static Row zero() { return Row{0ull}; }
+    __device__ bool any() const { return a != 0; }
+    // valid = ~occ restricted to columns [0, n)
+    __device__ Row free_below(int n) const { return Row{n <= 0 ? 0ull : (~a & (n >= 64 ? ~0ull : ((1ull << n) - 1ull)))}; }
+};
+template <> struct Row<2> {
+    u64 a, b;
+    __device__ static Row load(const u64 *p) { return Row{p[0], p[1]}; }
+    __device__ void store(u64 *p) const { p[0] = a; p[1] = b; }
+    __device__ Row operator|(Row o) const { return Row{a | o.a, b | o.b}; }
+    __device__ Row shr(int k) const {
+        if (k == 0) return *this;
+        if (k >= 128) return Row{0ull, 0ull};
+        if (k >= 64) return Row{b >> (k - 64), 0ull};
+        return Row{(a >> k) | (b << (64 - k)), b >> k};
+    }
+    __device__ static Row zero() { return Row{0ull, 0ull}; }
+    __device__ bool any() const { return (a | b) != 0; }
+    __device__ Row free_below(int n) const {
+        u64 ma = n <= 0 ? 0ull : (n >= 64 ? ~0ull : ((1ull << n) - 1ull));
+        u64 mb = n <= 64 ? 0ull : (n >= 128 ? ~0ull : ((1ull << (n - 64)) - 1ull));
+        return Row{~a & ma, ~b & mb};
+    }
+};
+
+// OR_{k < pw} (row >> k): bit j set iff some cell j..j+pw-1 of the row is occupied (log-step doubling).
+template <int WW> __device__ inline Row<WW> hfold(Row<WW> r, int pw) {
+    Row<WW> f = r;
+    int s = 1;
+    while (2 * s <= pw) { f = f | f.shr(s); s *= 2; }
+    if (s < pw) f = f | f.shr(pw - s);
+    return f;
+}
+
+// 4 mask bits -> 4 bytes of 0/1
+__device__ inline unsigned expand4(unsigned b) { return (b * 0x00204081u) & 0x01010101u; }
+__device__ inline uint4 expand16(unsigned bits) {
+    return make_uint4(expand4(bits & 15u), expand4((bits >> 4) & 15u), expand4((bits >> 8) & 15u), expand4((bits >> 12) & 15u));
+}
+
+// Write one H x W uint8 plane (0/1) from bit rows in LDS: 16 bytes per lane, 1 KiB per wave instruction.
+template <int WW> __device__ inline void emit_plane(unsigned char *dst, const u64 *bits, int H, int W, int lane) {
+    const int cells = H * W;
+    if ((W & 15) == 0 && (((uintptr_t)dst) & 15) == 0) {
+        uint4 *d4 = (uint4 *)dst;
+        for (int c = lane; c < cells / 16; c += WAVE) {
+            int cell = c * 16, r = cell / W, col = cell - r * W;
+            unsigned b = (unsigned)(bits[r * WW + (col >> 6)] >> (col & 63)) & 0xFFFFu;
+            d4[c] = expand16(b);
+        }
+    } else {  // odd widths (the reference's small test grids): byte path
+        for (int i = lane; i < cells; i += WAVE) {
+            int r = i / W, col = i - r * W;
+            dst[i] = (unsigned char)((bits[r * WW + (col >> 6)] >> (col & 63)) & 1ull);
+        }
+    }
+}
+__device__ inline void emit_zero(unsigned char *dst, long long bytes, int lane) {
+    if ((bytes & 15) == 0 && (((uintptr_t)dst) & 15) == 0) {
+        uint4 *d4 = (uint4 *)dst;
+        for (long long c = lane; c < bytes / 16; c += WAVE) d4[c] = make_uint4(0, 0, 0, 0);
+    } else {
+        for (long long i = lane; i < bytes; i += WAVE) dst[i] = 0;
+    }
+}
+
+// Legal-placement bit mask for a ph x pw window (R:526-567, S:1792-1835):
+// vm[r] bit j = 1 iff r <= H-ph and j <= W-pw and occ[r..r+ph-1][j..j+pw-1] is empty.
+// Returns (wave-uniform) whether any bit is set.
+template <int WW>
+__device__ inline bool window_mask(const u64 *occ, u64 *hf, u64 *vm, int H, int W, int ph, int pw, int lane) {
+    for (int r = lane; r < H; r += WAVE) hfold<WW>(Row<WW>::load(occ + r * WW), pw).store(hf + r * WW);
+    __syncthreads();
+    bool any = false;
+    for (int r = lane; r < H; r += WAVE) {
+        Row<WW> v = Row<WW>::zero();
+        if (r + ph <= H) {
+            Row<WW> acc = Row<WW>::load(hf + r * WW);
+            for (int k = 1; k < ph; k++) acc = acc | Row<WW>::load(hf + (r + k) * WW);
+            v = acc.free_below(W - pw + 1);
+        }
+        v.store(vm + r * WW);
+        any |= v.any();
+    }
+    __syncthreads();
+    return __any(any);
+}
+
+// ----------------------------------------------------------------------------------------------
+// float64 geometry of the reward (one IEEE operation per operator, see file header)
+// ----------------------------------------------------------------------------------------------
+// S:1288-1301 euclidean_distance == np.linalg.norm == sqrt(ddot): sqrt(fma(dy, dy, dx*dx))
+__device__ inline double norm2(double dx, double dy) { return __dsqrt_rn(__fma_rn(dy, dy, __dmul_rn(dx, dx))); }
+
+// S:653-702 is_intersect
+__device__ inline bool is_intersect(double x1, double y1, double x2, double y2, double x3, double y3, double x4, double y4) {
+    if ((x1 == x3 && y1 == y3) || (x1 == x4 && y1 == y4) || (x2 == x3 && y2 == y3) || (x2 == x4 && y2 == y4)) return true;
+    double det = (x1 - x2) * (y3 - y4) - (y1 - y2) * (x3 - x4);
+    if (det == 0) return false;
+    double a = x1 * y2 - y1 * x2, b = x3 * y4 - y3 * x4;
+    double x = (a * (x3 - x4) - (x1 - x2) * b) / det;
+    double y = (a * (y3 - y4) - (y1 - y2) * b) / det;
+    return fmin(x1, x2) <= x && x <= fmax(x1, x2) && fmin(x3, x4) <= x && x <= fmax(x3, x4) &&
+           fmin(y1, y2) <= y && y <= fmax(y1, y2) && fmin(y3, y4) <= y && y <= fmax(y3, y4);
+}
+
+// Centroid routing + intersections + wirelength for one environment (S:1243-1271, :629-651, :704-722).
+// Segment q belongs to pin q: (pin q, centroid of its net); a 2-pin net has the single segment (p0, p1)
+// carried by its first pin.  seg layout in LDS: x1[P] y1[P] x2[P] y2[P] dist[P] then int active/net [P].
+__device__ inline void route_centroid(const DevParams &p, const EnvHdr *hdr, const PinRec *pins, double *seg,
+                                      int lane, double *wirelength, int *nintersections) {
+    const int P = p.P, np = hdr->npins, nn = hdr->nnets;
+    double *X1 = seg, *Y1 = seg + P, *X2 = seg + 2 * P, *Y2 = seg + 3 * P, *D = seg + 4 * P;
+    double *cen = seg + 5 * P;             // cx[MAX_NETS], cy[MAX_NETS]
+    int *act = (int *)(cen + 2 * PCBENV_MAX_NETS);  // 1 = carries a segment
+    int *nstart = act + P;                 // [nnets + 1]
+    for (int q = lane; q < np; q += WAVE)
+        if (q == 0 || pins[q].net != pins[q - 1].net) nstart[pins[q].net] = q;
+    if (lane == 0) nstart[nn] = np;
+    __syncthreads();
+    for (int n = lane; n < nn; n += WAVE) {  // get_centroid: exact integer sums, one division each
+        int s = nstart[n], e = nstart[n + 1];
+        double sx = 0, sy = 0;
+        for (int q = s; q < e; q++) { sx += (double)pins[q].abs_x; sy += (double)pins[q].abs_y; }
+        cen[n] = sx / (double)(e - s);
+        cen[PCBENV_MAX_NETS + n] = sy / (double)(e - s);
+    }
+    __syncthreads();
+    for (int q = lane; q < np; q += WAVE) {
+        int n = pins[q].net, s = nstart[n], cnt = nstart[n + 1] - s;
+        double x1 = pins[q].abs_x, y1 = pins[q].abs_y, x2, y2;
+        int a = 1;
+        if (cnt == 2) {
+            a = (q == s);
+            x2 = pins[s + 1].abs_x; y2 = pins[s + 1].abs_y;
+        } else {
+            x2 = cen[n]; y2 = cen[PCBENV_MAX_NETS + n];
+        }
+        X1[q] = x1; Y1[q] = y1; X2[q] = x2; Y2[q] = y2; act[q] = a;
+        D[q] = norm2(x1 - x2, y1 - y2);
+    }
+    __syncthreads();
+    int cnt = 0;
+    for (int i = 0; i < np; i++) {
+        if (!act[i]) continue;
+        const int ni = pins[i].net;
+        const double x1 = X1[i], y1 = Y1[i], x2 = X2[i], y2 = Y2[i];
+        for (int j = nstart[ni + 1] + lane; j < np; j += WAVE)  // segments of later nets only
+            if (act[j] && is_intersect(x1, y1, x2, y2, X1[j], Y1[j], X2[j], Y2[j])) cnt++;
+    }
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    double wl = 0.0;  // sequential sum in route order (bit-exact with the reference's python float loop)
+    for (int q = 0; q < np; q++) if (act[q]) wl += D[q];
+    *wirelength = wl;
+    *nintersections = cnt;
+}
+
+// ----------------------------------------------------------------------------------------------
+// shared pieces of reset / step
+// ----------------------------------------------------------------------------------------------
+struct Lds {
+    EnvHdr *hdr; u64 *occ, *vm; CompRec *comps; PinRec *pins;
+    u64 *hf; unsigned char *cls; double *seg;
+};
+__device__ inline Lds carve(unsigned char *smem, const DevParams &p) {
+    Lds l;
+    l.hdr = (EnvHdr *)smem;
+    l.occ = (u64 *)(smem + p.offOcc);
+    l.vm = (u64 *)(smem + p.offVm);
+    l.comps = (CompRec *)(smem + p.offComps);
+    l.pins = (PinRec *)(smem + p.offPins);
+    l.hf = (u64 *)(smem + p.ldsHf);
+    l.cls = smem + p.ldsCls;
+    l.seg = (double *)(smem + p.ldsSeg);
+    return l;
+}
+__device__ inline void load_state(unsigned char *smem, const DevParams &p, int e, int lane) {
+    const uint4 *src = (const uint4 *)(p.state + (size_t)e * p.stateStride);
+    uint4 *dst = (uint4 *)smem;
+    for (int i = lane; i < (int)(p.stateStride / 16); i += WAVE) dst[i] = src[i];
+    __syncthreads();
+}
+__device__ inline void store_state(const unsigned char *smem, const DevParams &p, int e, int lane) {
+    __syncthreads();
+    uint4 *dst = (uint4 *)(p.state + (size_t)e * p.stateStride);
+    const uint4 *src = (const uint4 *)smem;
+    for (int i = lane; i < (int)(p.stateStride / 16); i += WAVE) dst[i] = src[i];
+}
+
+// Mask of the current component (or zeros) into l.vm, both orientations.  Returns "some action is legal".
+template <int KIND, int WW> __device__ inline bool current_mask(const DevParams &p, Lds &l, int lane) {
+    const int H = p.H, W = p.W, plane = H * WW;
+    const int cur = l.hdr->cur;
+    bool any = false;
+    if (KIND == PCBENV_SQUARE) {
+        any = window_mask<WW>(l.occ, l.hf, l.vm, H, W, p.component_n, p.component_n, lane);
+    } else if (cur >= 0) {
+        const int h = l.comps[cur].h, w = l.comps[cur].w;
+        any = window_mask<WW>(l.occ, l.hf, l.vm, H, W, h, w, lane);
+        if (h == w) {
+            for (int i = lane; i < plane; i += WAVE) l.vm[plane + i] = l.vm[i];
+            __syncthreads();
+        } else {
+            any |= window_mask<WW>(l.occ, l.hf, l.vm + plane, H, W, w, h, lane);
+        }
+    } else {
+        for (int i = lane; i < 2 * plane; i += WAVE) l.vm[i] = 0ull;
+        __syncthreads();
+    }
+    return any;
+}
+
+// grid + action_mask planes (+ pin_grid for the spatial kind) of environment e from LDS state.
+template <int KIND, int WW> __device__ inline void emit_cells(const DevParams &p, Lds &l, int e, int lane, bool with_grid) {
+    const int H = p.H, W = p.W, HW = H * W, plane = H * WW;
+    if (with_grid && p.buf.grid) emit_plane<WW>(p.buf.grid + (size_t)e * HW, l.occ, H, W, lane);
+    if (p.buf.action_mask) {
+        unsigned char *m = p.buf.action_mask + (size_t)e * p.O * HW;
+        emit_plane<WW>(m, l.vm, H, W, lane);
+        if (KIND != PCBENV_SQUARE) emit_plane<WW>(m + HW, l.vm + plane, H, W, lane);
+        if (KIND == PCBENV_PIN || KIND == PCBENV_SPATIAL) {  // S:1852-1853 mask[2] = mask[0], mask[3] = mask[1]
+            emit_plane<WW>(m + 2 * HW, l.vm, H, W, lane);
+            emit_plane<WW>(m + 3 * HW, l.vm + plane, H, W, lane);
+        }
+    }
+}
+
+// S:1663-1675 draw_pins: class map (0 empty, 1 occupied without pin, n+2 pin of net n) -> one-hot[:, :, 1:]
+template <int WW> __device__ inline void emit_pin_grid(const DevParams &p, Lds &l, int e, int lane) {
+    if (!p.buf.pin_grid) return;
+    const int H = p.H, W = p.W, HW = H * W, K = p.K;
+    for (int i = lane; i < HW; i += WAVE) {
+        int r = i / W, c = i - r * W;
+        l.cls[i] = (unsigned char)((l.occ[r * WW + (c >> 6)] >> (c & 63)) & 1ull);
+    }
+    __syncthreads();
+    for (int q = lane; q < l.hdr->npins; q += WAVE) {
+        const PinRec pr = l.pins[q];
+        if (pr.abs_x >= 0 && pr.abs_y >= 0) l.cls[pr.abs_x * W + pr.abs_y] = (unsigned char)(pr.net + 2);
+    }
+    __syncthreads();
+    unsigned char *dst = p.buf.pin_grid + (size_t)e * HW * K;
+    const long long bytes = (long long)HW * K;
+    if ((bytes & 15) == 0 && (((uintptr_t)dst) & 15) == 0) {
+        uint4 *d4 = (uint4 *)dst;
+        for (int c = lane; c < (int)(bytes / 16); c += WAVE) {
+            int b0 = c * 16, cell = b0 / K, ch = b0 - cell * K;
+            unsigned w[4] = {0, 0, 0, 0};
+            unsigned cl = l.cls[cell];
+            #pragma unroll
+            for (int k = 0; k < 16; k++) {
+                w[k >> 2] |= (unsigned)(cl == (unsigned)(ch + 1)) << (8 * (k & 3));
+                if (++ch == K) { ch = 0; cell++; cl = cell < HW ? l.cls[cell] : 0; }
+            }
+            d4[c] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    } else {
+        for (long long i = lane; i < bytes; i += WAVE) {
+            int cell = (int)(i / K), ch = (int)(i - (long long)cell * K);
+            dst[i] = (unsigned char)(l.cls[cell] == ch + 1);
+        }
+    }
+}
+
+// Feature rows of one pin (P:72-103 / S:70-104 Pin.calculate_feature): [rel_x, rel_y, abs_x, abs_y]
+template <int KIND> __device__ inline void write_pin_num(const DevParams &p, int e, const PinRec &pr) {
+    if (!p.buf.all_pins_num_feature) return;
+    int row;
+    if (KIND == PCBENV_SPATIAL) row = pr.id & PIN_ID_MASK;
+    else { if (pr.id & PIN_LOSER) return; row = pr.comp * p.mp + (pr.id & PIN_ID_MASK); }
+    double *f = p.buf.all_pins_num_feature + ((size_t)e * p.pinRows + row) * 4;
+    f[0] = pr.rel_x; f[1] = pr.rel_y; f[2] = pr.abs_x; f[3] = pr.abs_y;
+}
+
+// Terminal reward (S:793-929 find_reward).  beam / both routes are left to k_reward_routes.
+template <int KIND>
+__device__ inline void terminal_reward(const DevParams &p, Lds &l, int e, int lane) {
+    const bool placed_all = l.hdr->cur < 0;
+    double reward, wl, ni;
+    if (!placed_all) {  // S:853-863 worst case: the upper bounds, normalised (spatial: twice, quirk Q3)
+        reward = -p.w_wl * (p.max_wl / p.wl_norm) - p.w_int * (p.max_int / p.int_norm);
+        wl = p.max_wl; ni = p.max_int;
+    } else if (p.reward_type == PCBENV_REWARD_CENTROID) {
+        double wsum; int cnt;
+        route_centroid(p, l.hdr, l.pins, l.seg, lane, &wsum, &cnt);
+        wl = wsum / p.wl_norm;
+        ni = (double)cnt / p.int_norm;
+        reward = -1 * (p.w_wl * wl + p.w_int * ni);
+    } else {
+        if (lane == 0) p.pending[e] = 1;
+        return;
+    }
+    if (lane == 0) {
+        p.buf.reward[e] = reward;
+        if (p.buf.info) { p.buf.info[2 * e] = wl; p.buf.info[2 * e + 1] = ni; }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// reset kernel (R:310-351, P:1544-1597, S:1487-1549, Q:74-113)
+// ----------------------------------------------------------------------------------------------
+template <int KIND, int WW>
+__global__ __launch_bounds__(WAVE) void k_reset(DevParams p, const unsigned char *__restrict__ mask) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int e = blockIdx.x, lane = threadIdx.x;
+    if (mask && !mask[e]) return;
+    Lds l = carve(smem, p);
+    const int H = p.H, W = p.W, HW = H * W;
+    // header first (cursor / episode survive a reset)
+    if (lane == 0) *l.hdr = *(const EnvHdr *)(p.state + (size_t)e * p.stateStride);
+    __syncthreads();
+    for (int i = lane; i < H * WW; i += WAVE) l.occ[i] = 0ull;
+    if (KIND != PCBENV_SQUARE) {
+        const unsigned slot = l.hdr->qcursor % (unsigned)p.Q;
+        const unsigned char *rec = p.queue + ((size_t)slot * p.B + e) * p.instStride;
+        const int *ih = (const int *)rec;
+        const int nc = ih[0], nn = ih[1], np = ih[2];
+        const unsigned char *crec = rec + 16, *prec = rec + 16 + 8 * (size_t)p.C;
+        for (int c = lane; c < p.C; c += WAVE) {
+            CompRec cr; cr.h = crec[8 * c]; cr.w = crec[8 * c + 1]; cr.px = -1; cr.py = -1;
+            cr.pad[0] = cr.pad[1] = cr.pad[2] = cr.pad[3] = 0;
+            if (c >= nc) { cr.h = 0; cr.w = 0; }
+            l.comps[c] = cr;
+        }
+        for (int q = lane; q < p.P; q += WAVE) {
+            PinRec pr; pr.rel_x = prec[8 * q]; pr.rel_y = prec[8 * q + 1]; pr.abs_x = -1; pr.abs_y = -1;
+            pr.net = prec[8 * q + 2]; pr.comp = prec[8 * q + 3];
+            pr.id = (unsigned short)(prec[8 * q + 4] | (prec[8 * q + 5] << 8));
+            if (q >= np) { pr.rel_x = pr.rel_y = 0; pr.net = 0xFF; pr.comp = 0xFF; pr.id = 0; }
+            l.pins[q] = pr;
+        }
+        if (lane == 0) {
+            l.hdr->ncomp = (short)nc; l.hdr->nnets = (short)nn; l.hdr->npins = (short)np; l.hdr->cur = 0;
+            l.hdr->qcursor += 1; l.hdr->episode += 1;
+        }
+        __syncthreads();
+        if (KIND == PCBENV_PIN) {  // quirk Q1: rows [component, pin_id] collide; the last writer in self.pins order wins
+            for (int q = lane; q < np; q += WAVE) {
+                bool loser = false;
+                for (int r = q + 1; r < np; r++)
+                    loser |= (l.pins[r].comp == l.pins[q].comp && (l.pins[r].id & PIN_ID_MASK) == (l.pins[q].id & PIN_ID_MASK));
+                if (loser) l.pins[q].id |= PIN_LOSER;
+            }
+        }
+    } else if (lane == 0) {
+        l.hdr->ncomp = 0; l.hdr->nnets = 0; l.hdr->npins = 0; l.hdr->cur = 0; l.hdr->episode += 1;
+    }
+    __syncthreads();
+    current_mask<KIND, WW>(p, l, lane);
+    emit_cells<KIND, WW>(p, l, e, lane, true);
+
+    if (KIND != PCBENV_SQUARE) {
+        const int nc = l.hdr->ncomp, np = l.hdr->npins;
+        // all_components_feature (R:60-79, S:203-239): [h, w, -1, -1, area/(H*W), (spatial: pin ids, -1 pad)]; absent rows 0
+        if (p.buf.all_components_feature) {
+            double *cf = p.buf.all_components_feature + (size_t)e * p.C * p.F;
+            for (int i = lane; i < p.C * p.F; i += WAVE) {
+                int c = i / p.F, k = i - c * p.F;
+                double v = 0.0;
+                if (c < nc) {
+                    const CompRec cr = l.comps[c];
+                    if (k == 0) v = cr.h; else if (k == 1) v = cr.w; else if (k == 2 || k == 3) v = -1.0;
+                    else if (k == 4) v = (double)(cr.h * cr.w) / p.area; else v = -1.0;
+                }
+                cf[i] = v;
+            }
+            if (KIND == PCBENV_SPATIAL) {  // pin ids of component.pins (self.pins order)
+                __syncthreads();
+                __threadfence_block();
+                for (int c = lane; c < nc; c += WAVE) {
+                    int k = 0;
+                    for (int q = 0; q < np; q++) if (l.pins[q].comp == c) cf[c * p.F + 5 + k++] = (double)(l.pins[q].id & PIN_ID_MASK);
+                }
+            }
+        }
+        if (p.buf.placement_mask) {
+            double *pm = p.buf.placement_mask + (size_t)e * p.C;
+            for (int c = lane; c < p.C; c += WAVE)
+                pm[c] = KIND == PCBENV_RECT ? 0.0 : (c == 0 ? 3.0 : (c < nc ? 1.0 : 0.0));
+        }
+        if (KIND == PCBENV_RECT && p.buf.component_mask) {
+            double *cm = p.buf.component_mask + (size_t)e * p.C;
+            for (int c = lane; c < p.C; c += WAVE) cm[c] = c < nc ? 1.0 : 0.0;
+        }
+        if (KIND == PCBENV_PIN || KIND == PCBENV_SPATIAL) {
+            if (p.buf.all_pins_num_feature) {
+                double *f = p.buf.all_pins_num_feature + (size_t)e * p.pinRows * 4;
+                for (int i = lane; i < p.pinRows * 4; i += WAVE) f[i] = 0.0;
+            }
+            if (p.buf.all_pins_cat_feature) {
+                double *f = p.buf.all_pins_cat_feature + (size_t)e * p.pinRows * p.catW;
+                for (int i = lane; i < p.pinRows * p.catW; i += WAVE)
+                    f[i] = (KIND == PCBENV_SPATIAL && i >= (p.pinRows - 1) * p.catW) ? -1.0 : 0.0;  // S:1520
+            }
+            __syncthreads();
+            __threadfence_block();
+            for (int q = lane; q < np; q += WAVE) {
+                const PinRec pr = l.pins[q];
+                write_pin_num<KIND>(p, e, pr);
+                if (p.buf.all_pins_cat_feature) {
+                    if (KIND == PCBENV_SPATIAL) {
+                        double *f = p.buf.all_pins_cat_feature + ((size_t)e * p.pinRows + (pr.id & PIN_ID_MASK)) * 2;
+                        f[0] = pr.net; f[1] = pr.comp;
+                    } else if (!(pr.id & PIN_LOSER)) {
+                        p.buf.all_pins_cat_feature[(size_t)e * p.pinRows + pr.comp * p.mp + (pr.id & PIN_ID_MASK)] = pr.net;
+                    }
+                }
+            }
+        }
+        if (KIND == PCBENV_SPATIAL) {
+            if (p.buf.pin_grid) emit_zero(p.buf.pin_grid + (size_t)e * HW * p.K, (long long)HW * p.K, lane);  // S:1504
+            if (p.buf.component_grid) {  // S:1677-1697 draw_components (unrotated rel coords; channel 0 == 1)
+                const int cgsz = p.mh * p.mw * p.K;
+                unsigned char *cg = p.buf.component_grid + (size_t)e * p.C * cgsz;
+                for (int i = lane; i < p.C * cgsz; i += WAVE) {
+                    int c = i / cgsz, k = i % p.K;
+                    cg[i] = (unsigned char)(c < nc && k == 0);
+                }
+                __syncthreads();
+                __threadfence_block();
+                for (int q = lane; q < np; q += WAVE) {
+                    const PinRec pr = l.pins[q];
+                    cg[((size_t)pr.comp * p.mh * p.mw + pr.rel_x * p.mw + pr.rel_y) * p.K + pr.net + 1] = 1;
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+        p.buf.reward[e] = 0.0;
+        p.buf.done[e] = 0;
+        if (p.buf.info) { p.buf.info[2 * e] = nan(""); p.buf.info[2 * e + 1] = nan(""); }
+        if (p.pending) p.pending[e] = 0;
+    }
+    store_state(smem, p, e, lane);
+}
+
+// ----------------------------------------------------------------------------------------------
+// step kernel (R:353-432, P:1599-1710, S:1551-1661, Q:115-153)
+// ----------------------------------------------------------------------------------------------
+template <int KIND, int WW>
+__global__ __launch_bounds__(WAVE) void k_step(DevParams p, const int *__restrict__ actions, int fmt) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int e = blockIdx.x, lane = threadIdx.x;
+    const int H = p.H, W = p.W, HW = H * W, plane = H * WW;
+    load_state(smem, p, e, lane);
+    Lds l = carve(smem, p);
+
+    int o, x, y;
+    if (fmt == PCBENV_ACTION_FLAT) {  // utils/environment/env_wrappers.py:80-98, :184-199
+        const int a = actions[e];
+        if (a < 0 || a >= p.O * HW) { o = -1; x = y = 0; }
+        else { o = a / HW; const int r = a - o * HW; x = r / W; y = r - x * W; }
+    } else {
+        o = actions[3 * e]; x = actions[3 * e + 1]; y = actions[3 * e + 2];
+        if (KIND == PCBENV_SQUARE) o = 0;
+    }
+    const int cur = l.hdr->cur;
+    // validate_action (S:1699-1723): action_mask[o, x, y] == 1; anything out of range is invalid
+    bool valid = o >= 0 && o < p.O && x >= 0 && x < H && y >= 0 && y < W && (KIND == PCBENV_SQUARE || cur >= 0);
+    if (valid) valid = (l.vm[(o & 1) * plane + x * WW + (y >> 6)] >> (y & 63)) & 1ull;
+
+    if (lane == 0 && p.buf.info) { p.buf.info[2 * e] = nan(""); p.buf.info[2 * e + 1] = nan(""); }
+    if (lane == 0 && p.pending) p.pending[e] = 0;
+    __syncthreads();
+
+    if (!valid) {  // terminal transition, state and observations unchanged (quirk Q8 iii)
+        if (lane == 0) p.buf.done[e] = 1;
+        if (KIND == PCBENV_SQUARE || KIND == PCBENV_RECT) { if (lane == 0) p.buf.reward[e] = 0.0; }
+        else terminal_reward<KIND>(p, l, e, lane);
+        return;
+    }
+
+    int ph, pw;
+    if (KIND == PCBENV_SQUARE) ph = pw = p.component_n;
+    else {
+        const CompRec cr = l.comps[cur];
+        ph = (o & 1) ? cr.w : cr.h;  // S:1742-1747 update_grid
+        pw = (o & 1) ? cr.h : cr.w;
+    }
+    // update_grid: rows x..x+ph-1, columns y..y+pw-1
+    for (int r = x + lane; r < x + ph && r < H; r += WAVE) {
+        for (int w = 0; w < WW; w++) {
+            const int lo = max(y, 64 * w) - 64 * w, hi = min(y + pw, 64 * w + 64) - 64 * w;  // bit range in word w
+            if (hi > lo) l.occ[r * WW + w] |= ((hi - lo) >= 64 ? ~0ull : ((1ull << (hi - lo)) - 1ull)) << lo;
+        }
+    }
+    if (KIND != PCBENV_SQUARE) {
+        if (lane == 0) { l.comps[cur].px = (signed char)x; l.comps[cur].py = (signed char)y; }
+        if (KIND == PCBENV_PIN || KIND == PCBENV_SPATIAL) {
+            const int ch = l.comps[cur].h, cw = l.comps[cur].w;
+            for (int q = lane; q < l.hdr->npins; q += WAVE) {  // S:149-190 place_component
+                PinRec pr = l.pins[q];
+                if (pr.comp != cur) continue;
+                const int rx = pr.rel_x, ry = pr.rel_y;
+                if (o == 1) { pr.rel_x = ry; pr.rel_y = ch - rx - 1; }
+                else if (o == 2) { pr.rel_x = ch - rx - 1; pr.rel_y = cw - ry - 1; }
+                else if (o == 3) { pr.rel_x = cw - ry - 1; pr.rel_y = rx; }
+                pr.abs_x = (signed char)(x + pr.rel_x); pr.abs_y = (signed char)(y + pr.rel_y);
+                l.pins[q] = pr;
+                write_pin_num<KIND>(p, e, pr);
+            }
+        }
+        if (lane == 0) {
+            if (p.buf.all_components_feature) {
+                double *cf = p.buf.all_components_feature + ((size_t)e * p.C + cur) * p.F;
+                cf[2] = x; cf[3] = y;
+            }
+            const int next = cur + 1 < l.hdr->ncomp ? cur + 1 : -1;
+            if (p.buf.placement_mask) {
+                double *pm = p.buf.placement_mask + (size_t)e * p.C;
+                pm[cur] = KIND == PCBENV_RECT ? 1.0 : 2.0;
+                if (next >= 0 && KIND != PCBENV_RECT) pm[next] = 3.0;
+            }
+            l.hdr->cur = (short)next;
+        }
+    }
+    __syncthreads();
+    const bool any = current_mask<KIND, WW>(p, l, lane);
+    emit_cells<KIND, WW>(p, l, e, lane, true);
+    if (KIND == PCBENV_SPATIAL) emit_pin_grid<WW>(p, l, e, lane);
+
+    const bool done = KIND == PCBENV_SQUARE ? !any : (l.hdr->cur < 0 || !any);  // S:1856-1869
+    if (lane == 0) p.buf.done[e] = done ? 1 : 0;
+    if (KIND == PCBENV_SQUARE || KIND == PCBENV_RECT) { if (lane == 0) p.buf.reward[e] = 1.0; }
+    else if (!done) { if (lane == 0) p.buf.reward[e] = 0.0; }
+    else terminal_reward<KIND>(p, l, e, lane);
+    store_state(smem, p, e, lane);
+}
+
+// ----------------------------------------------------------------------------------------------
+// uniform legal-action sampler (rollout driver; agent/random/random_policy_*.py counterpart)
+// ----------------------------------------------------------------------------------------------
+__device__ inline u64 mix64(u64 z) {  // splitmix64 finaliser
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ inline int select_bit(u64 w, int k) {  // position of the k-th (0-based) set bit
+    for (int i = 0; i < k; i++) w &= w - 1;
+    return __ffsll((long long)w) - 1;
+}
+__global__ __launch_bounds__(WAVE) void k_sample(DevParams p, int *__restrict__ actions, int fmt, u64 seed,
+                                                 u64 first_env, u64 step_index) {
+    const int e = blockIdx.x, lane = threadIdx.x;
+    const int H = p.H, WW = p.WW, HW = H * p.W, plane = H * WW;
+    const u64 *vm = (const u64 *)(p.state + (size_t)e * p.stateStride + p.offVm);
+    const int nplanes = p.kind == PCBENV_SQUARE ? 1 : 2;
+    const int words = nplanes * plane;
+    // per-lane popcount over a contiguous chunk of words, then wave prefix sum
+    const int per = (words + WAVE - 1) / WAVE;
+    int mine = 0;
+    for (int i = lane * per; i < (lane + 1) * per && i < words; i++) mine += __popcll(vm[i]);
+    int incl = mine;
+    for (int d = 1; d < WAVE; d <<= 1) { int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+    const int total = __shfl(incl, WAVE - 1);
+    int o = 0, x = 0, y = 0;
+    if (total > 0) {
+        const u64 rnd = mix64(mix64(seed ^ 0x9E3779B97F4A7C15ull * (first_env + (u64)e + 1)) + step_index);
+        const int reps = (p.kind == PCBENV_PIN || p.kind == PCBENV_SPATIAL) ? 2 : 1;  // orientations 2, 3 mirror 0, 1
+        const unsigned pick = (unsigned)(((rnd >> 32) * (u64)(total * reps)) >> 32);
+        const int k = (int)(pick % (unsigned)total), rep = (int)(pick / (unsigned)total);
+        const int excl = incl - mine;
+        const bool owner = k >= excl && k < incl;
+        int found = -1;
+        if (owner) {
+            int rem = k - excl;
+            for (int i = lane * per; i < (lane + 1) * per && i < words; i++) {
+                int c = __popcll(vm[i]);
+                if (rem < c) { found = i * 64 + select_bit(vm[i], rem); break; }
+                rem -= c;
+            }
+        }
+        const u64 ball = __ballot(owner);
+        const int src = __ffsll((long long)ball) - 1;
+        found = __shfl(found, src);
+        const int word = found >> 6, bit = found & 63;
+        const int pl = word / plane, rw = word - pl * plane;
+        o = pl + 2 * rep; x = rw / WW; y = (rw - x * WW) * 64 + bit;
+    }
+    if (lane == 0) {
+        if (fmt == PCBENV_ACTION_FLAT) actions[e] = o * HW + x * p.W + y;
+        else { actions[3 * e] = o; actions[3 * e + 1] = x; actions[3 * e + 2] = y; }
+    }
+}
+
+// ==============================================================================================
+// host side: the C ABI (include/pcbenv.h)
+// ==============================================================================================
+struct pcbenv {
+    pcbenv_config cfg;
+    int device;
+    DevParams dp;
+    bool bound;
+    unsigned loaded_slots;  // bit s = slot s loaded for all environments at least once
+    char err[256];
+};
+
+static char g_err[256] = "";
+static int fail(pcbenv *env, int code, const char *fmt, const char *detail = "") {
+    char *dst = env ? env->err : g_err;
+    snprintf(dst, 256, fmt, detail);
+    if (env) snprintf(g_err, 256, "%s", dst);
+    return code;
+}
+#define HIP_TRY(env, call)                                                          \
+    do {                                                                            \
+        hipError_t e_ = (call);                                                     \
+        if (e_ != hipSuccess) return fail(env, PCBENV_EHIP, #call ": %s", hipGetErrorString(e_)); \
+    } while (0)
+
+static int align16(long long v) { return (int)((v + 15) & ~15ll); }
+
+extern "C" int pcbenv_abi_version(void) { return PCBENV_ABI_VERSION; }
+
+extern "C" const char *pcbenv_last_error(const pcbenv *env) { return env ? env->err : g_err; }
+
+static bool is_pin_kind(int k) { return k == PCBENV_PIN || k == PCBENV_SPATIAL; }
+
+extern "C" int32_t pcbenv_max_total_pins(const pcbenv_config *c) {
+    if (!c || !is_pin_kind(c->kind)) return 0;
+    long long a = (long long)c->max_num_pins_per_net * c->max_num_nets;
+    long long b = (long long)c->max_num_components * c->max_component_h * c->max_component_w;
+    return (int32_t)(a < b ? a : b);
+}
+extern "C" int64_t pcbenv_instance_stride(const pcbenv_config *c) {
+    if (!c || c->kind == PCBENV_SQUARE) return 0;
+    return 16 + 8ll * (c->max_num_components + pcbenv_max_total_pins(c));
+}
+
+// The reference constructors' checks (quirk Q6), then the HIP path's limits.
+static int validate(const pcbenv_config *c) {
+    if (c->kind < PCBENV_SQUARE || c->kind > PCBENV_SPATIAL) return fail(0, PCBENV_EINVAL, "unknown environment kind");
+    if (c->height < 0 || c->width < 0) return fail(0, PCBENV_EINVAL, "Grid size must not be negative.");
+    if (c->num_envs < 1) return fail(0, PCBENV_EINVAL, "num_envs must be at least 1");
+    if (c->kind == PCBENV_SQUARE) {
+        if (c->component_n > c->height || c->component_n > c->width)
+            return fail(0, PCBENV_EINVAL, "Component size must not exceed the grid size.");
+        if (c->component_n < 1) return fail(0, PCBENV_ELIMIT, "component_n must be at least 1");
+    } else {
+        bool too_big = c->kind == PCBENV_PIN ? (c->max_component_w > c->width || c->max_component_h > c->height)
+                                             : (c->max_component_w > c->height || c->max_component_h > c->width);
+        if (too_big) return fail(0, PCBENV_EINVAL, "Component size must not exceed the grid size.");
+        if (c->min_component_w < 1 || c->min_component_h < 1) return fail(0, PCBENV_EINVAL, "Component size must be at least 1.");
+        if (c->max_num_components < 1 || c->max_num_components > c->height * c->width)
+            return fail(0, PCBENV_EINVAL, "Number of components must be in [1, grid area].");
+    }
+    if (c->kind == PCBENV_PIN) {
+        if (c->min_num_pins_per_net > c->max_num_pins_per_net) return fail(0, PCBENV_EINVAL, "min_num_pins_per_net must not exceed max_num_pins_per_net.");
+        if (c->min_num_pins_per_net < 2) return fail(0, PCBENV_EINVAL, "min_num_pins_per_net must be at least 2.");
+        if (c->min_num_pins_per_net * c->min_num_nets > c->min_component_w * c->min_component_h * c->min_num_components)
+            return fail(0, PCBENV_EINVAL, "min_num_pins_per_net * min_num_nets exceeds the minimum total component area.");
+        if (c->reward_beam_width < 1) return fail(0, PCBENV_EINVAL, "Beam width must be a positive integer.");
+        if (c->reward_type < 0 || c->reward_type > 2) return fail(0, PCBENV_EINVAL, "Reward type must be 'beam', 'centroid' or 'both'.");
+    }
+    if (c->kind == PCBENV_SPATIAL) {
+        if (c->reward_type < 0 || c->reward_type > 2) return fail(0, PCBENV_EINVAL, "Reward type must be 'beam', 'centroid' or 'both'.");
+        if (c->reward_beam_width < 2 || c->reward_beam_width > c->max_num_pins_per_net)
+            return fail(0, PCBENV_EINVAL, "Beam width must be an integer in [2, max_num_pins_per_net].");
+        if (c->weight_wirelength < 0) return fail(0, PCBENV_EINVAL, "weight_wirelength must not be negative.");
+    }
+    // limits of this implementation
+    if (c->height < 1 || c->width < 1 || c->height > PCBENV_MAX_SIDE || c->width > PCBENV_MAX_SIDE)
+        return fail(0, PCBENV_ELIMIT, "grid side must be in [1, 128]");
+    if (c->queue_depth < 1 || c->queue_depth > 32) return fail(0, PCBENV_ELIMIT, "queue_depth must be in [1, 32]");
+    if (c->kind != PCBENV_SQUARE) {
+        int side = c->max_component_h > c->max_component_w ? c->max_component_h : c->max_component_w;
+        int shorter = c->height < c->width ? c->height : c->width;
+        if (side > shorter) return fail(0, PCBENV_ELIMIT, "a component side exceeds the shorter grid side (the reference raises inside convolve2d)");
+        if (c->max_num_components > PCBENV_MAX_COMPONENTS) return fail(0, PCBENV_ELIMIT, "too many components");
+        if (c->min_num_components < 1 || c->min_num_components > c->max_num_components) return fail(0, PCBENV_ELIMIT, "min_num_components must be in [1, max_num_components]");
+        if (c->min_component_h > c->max_component_h || c->min_component_w > c->max_component_w) return fail(0, PCBENV_ELIMIT, "min component size exceeds max");
+    }
+    if (is_pin_kind(c->kind)) {
+        if (pcbenv_max_total_pins(c) > PCBENV_MAX_PINS || c->max_num_nets > PCBENV_MAX_NETS) return fail(0, PCBENV_ELIMIT, "too many pins or nets");
+        if (c->max_num_pins_per_net > PCBENV_MAX_PINS_PER_NET) return fail(0, PCBENV_ELIMIT, "too many pins per net");
+        if (c->max_component_h * c->max_component_w > PCBENV_MAX_PINS_PER_COMPONENT) return fail(0, PCBENV_ELIMIT, "too many pins per component");
+        if (c->min_num_pins_per_net < 1 || c->min_num_nets < 1 || c->min_num_nets > c->max_num_nets) return fail(0, PCBENV_ELIMIT, "nets / pins per net must be at least 1");
+        if (c->reward_type != PCBENV_REWARD_CENTROID && c->reward_beam_width > PCBENV_MAX_BEAM_WIDTH) return fail(0, PCBENV_ELIMIT, "beam width above 4");
+    }
+    return PCBENV_OK;
+}
+
+static double mean2(int a, int b) { return (double)(a + b) / 2.0; }
+
+extern "C" int pcbenv_create(const pcbenv_config *cfg, int device, pcbenv **out) {
+    if (out) *out = 0;
+    if (!cfg || !out) return fail(0, PCBENV_EINVAL, "null argument");
+    int rc = validate(cfg);
+    if (rc != PCBENV_OK) return rc;
+    pcbenv *env = new pcbenv();
+    memset(env, 0, sizeof(*env));
+    env->cfg = *cfg;
+    env->device = device;
+    if (is_pin_kind(cfg->kind)) {  // P:467-468 / S:450-451: clipped after validation
+        env->cfg.net_distribution = cfg->net_distribution < 0 ? 0 : cfg->net_distribution > 9 ? 9 : cfg->net_distribution;
+        env->cfg.pin_spread = cfg->pin_spread < 0 ? 0 : cfg->pin_spread > 9 ? 9 : cfg->pin_spread;
+    }
+    DevParams &d = env->dp;
+    const pcbenv_config &c = env->cfg;
+    d.kind = c.kind; d.H = c.height; d.W = c.width; d.WW = (c.width + 63) / 64;
+    d.O = c.kind == PCBENV_SQUARE ? 1 : c.kind == PCBENV_RECT ? 2 : 4;
+    d.C = c.kind == PCBENV_SQUARE ? 0 : c.max_num_components;
+    d.P = pcbenv_max_total_pins(&c);
+    d.N = is_pin_kind(c.kind) ? c.max_num_nets : 0; d.K = d.N + 1;
+    d.mh = c.max_component_h; d.mw = c.max_component_w; d.mp = d.mh * d.mw;
+    d.F = c.kind == PCBENV_SPATIAL ? 5 + d.mp : 5;
+    d.pinRows = c.kind == PCBENV_PIN ? d.C * d.mp : c.kind == PCBENV_SPATIAL ? d.C * d.mp + 1 : 0;
+    d.catW = c.kind == PCBENV_SPATIAL ? 2 : 1;
+    d.B = c.num_envs; d.Q = c.queue_depth;
+    d.reward_type = c.reward_type; d.beam_width = c.reward_beam_width; d.component_n = c.component_n;
+    d.flags = c.flags;
+    d.w_wl = c.weight_wirelength; d.w_int = c.weight_num_intersections;
+    d.area = (double)(c.height * c.width);
+    if (is_pin_kind(c.kind)) {  // a15 (S:724-791, P:757-830) and the normalisers of find_reward (S:839-850)
+        double dist = sqrt(fma((double)c.width, (double)c.width, (double)c.height * (double)c.height));
+        double total = 0.5 * dist * (double)(c.max_num_nets * c.max_num_pins_per_net);
+        d.max_wl = c.kind == PCBENV_SPATIAL ? total / (double)(c.height + c.width) : total;
+        double mi = 0.5 * (double)(c.max_num_pins_per_net * c.max_num_pins_per_net) * (double)c.max_num_nets * (double)(c.max_num_nets - 1);
+        d.max_int = c.kind == PCBENV_PIN ? (double)(long long)mi : mi;
+        d.wl_norm = (double)(c.height + c.width);
+        double a = mean2(c.min_component_h, c.max_component_h) * mean2(c.min_component_w, c.max_component_w) * mean2(c.min_num_components, c.max_num_components);
+        double b = mean2(c.min_num_pins_per_net, c.max_num_pins_per_net) * mean2(c.min_num_nets, c.max_num_nets);
+        d.int_norm = a < b ? a : b;
+    }
+    // state block: header | occ | vm | comps | pins
+    d.offOcc = HDR_BYTES;
+    d.offVm = d.offOcc + d.H * d.WW * 8;
+    d.offComps = d.offVm + 2 * d.H * d.WW * 8;
+    d.offPins = d.offComps + 8 * d.C;
+    d.stateStride = align16((long long)d.offPins + 8ll * d.P);
+    d.instStride = align16(pcbenv_instance_stride(&c));
+    // LDS scratch behind the state mirror
+    d.ldsHf = (int)d.stateStride;
+    d.ldsCls = d.ldsHf + d.H * d.WW * 8;
+    d.ldsSeg = align16(d.ldsCls + (c.kind == PCBENV_SPATIAL ? d.H * d.W : 0));
+    d.ldsBytes = align16(d.ldsSeg + (is_pin_kind(c.kind) ? (5 * d.P + 2 * PCBENV_MAX_NETS) * 8 + (d.P + PCBENV_MAX_NETS + 2) * 4 : 0));
+    if (hipSetDevice(device) != hipSuccess) { int r = fail(0, PCBENV_EHIP, "hipSetDevice failed (no such device?)"); delete env; return r; }
+    size_t sbytes = (size_t)d.stateStride * d.B, qbytes = (size_t)d.instStride * d.B * d.Q;
+    if (hipMalloc((void **)&d.state, sbytes) != hipSuccess || hipMalloc((void **)&d.queue, qbytes ? qbytes : 16) != hipSuccess ||
+        hipMalloc((void **)&d.pending, (size_t)d.B) != hipSuccess) {
+        int r = fail(0, PCBENV_EHIP, "hipMalloc failed");
+        pcbenv_destroy(env);
+        return r;
+    }
+    hipMemset(d.state, 0, sbytes);
+    hipMemset(d.queue, 0, qbytes ? qbytes : 16);
+    hipMemset(d.pending, 0, (size_t)d.B);
+    hipDeviceSynchronize();
+    *out = env;
+    return PCBENV_OK;
+}
+
+extern "C" void pcbenv_destroy(pcbenv *env) {
+    if (!env) return;
+    hipSetDevice(env->device);
+    if (env->dp.state) hipFree(env->dp.state);
+    if (env->dp.queue) hipFree(env->dp.queue);
+    if (env->dp.pending) hipFree(env->dp.pending);
+    delete env;
+}
+
+extern "C" int pcbenv_bind_buffers(pcbenv *env, const pcbenv_buffers *b) {
+    if (!env || !b) return fail(env, PCBENV_EINVAL, "null argument");
+    if (!b->reward || !b->done) return fail(env, PCBENV_EINVAL, "reward and done buffers are required");
+    env->dp.buf = *b;
+    int k = env->cfg.kind;
+    if (k != PCBENV_SPATIAL) { env->dp.buf.pin_grid = 0; env->dp.buf.component_grid = 0; }
+    if (!is_pin_kind(k)) { env->dp.buf.all_pins_num_feature = 0; env->dp.buf.all_pins_cat_feature = 0; env->dp.buf.info = 0; }
+    if (k != PCBENV_RECT) env->dp.buf.component_mask = 0;
+    if (k == PCBENV_SQUARE) { env->dp.buf.all_components_feature = 0; env->dp.buf.placement_mask = 0; }
+    env->bound = true;
+    return PCBENV_OK;
+}
+
+extern "C" int pcbenv_load_instances(pcbenv *env, const int32_t *env_ids, int32_t n, int32_t slot,
+                                     const void *host_tables, void *stream) {
+    if (!env || !host_tables) return fail(env, PCBENV_EINVAL, "null argument");
+    const DevParams &d = env->dp;
+    if (env->cfg.kind == PCBENV_SQUARE) return PCBENV_OK;  // the square env has no instance
+    if (slot < 0 || slot >= d.Q || n < 0 || n > d.B) return fail(env, PCBENV_EINVAL, "slot or count out of range");
+    HIP_TRY(env, hipSetDevice(env->device));
+    const long long src_stride = pcbenv_instance_stride(&env->cfg);
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned char *src = (const unsigned char *)host_tables;
+    // sanity-check the records (bad tables would index out of bounds on the device)
+    for (int i = 0; i < n; i++) {
+        const int32_t *h = (const int32_t *)(src + (size_t)i * src_stride);
+        if (h[0] < 1 || h[0] > d.C || h[2] < 0 || h[2] > d.P || h[1] < 0 || h[1] > PCBENV_MAX_NETS)
+            return fail(env, PCBENV_EINVAL, "instance record out of range");
+        const unsigned char *cr = (const unsigned char *)h + 16, *pr = cr + 8 * (size_t)d.C;
+        for (int c = 0; c < h[0]; c++)
+            if (cr[8 * c] < 1 || cr[8 * c] > d.mh || cr[8 * c + 1] < 1 || cr[8 * c + 1] > d.mw) return fail(env, PCBENV_EINVAL, "component size out of range");
+        int prev = 0;
+        for (int q = 0; q < h[2]; q++) {
+            int net = pr[8 * q + 2], comp = pr[8 * q + 3];
+            if (comp >= h[0] || net >= h[1] || net < prev) return fail(env, PCBENV_EINVAL, "pin record out of range or not net-major");
+            if (pr[8 * q] >= cr[8 * comp] || pr[8 * q + 1] >= cr[8 * comp + 1]) return fail(env, PCBENV_EINVAL, "pin outside its component");
+            prev = net;
+        }
+    }
+    unsigned char *base = d.queue + (size_t)slot * d.B * d.instStride;
+    if (!env_ids && src_stride == d.instStride) {
+        HIP_TRY(env, hipMemcpyAsync(base, src, (size_t)n * src_stride, hipMemcpyHostToDevice, s));
+    } else {
+        for (int i = 0; i < n; i++) {
+            int id = env_ids ? env_ids[i] : i;
+            if (id < 0 || id >= d.B) return fail(env, PCBENV_EINVAL, "environment id out of range");
+            HIP_TRY(env, hipMemcpyAsync(base + (size_t)id * d.instStride, src + (size_t)i * src_stride, (size_t)src_stride, hipMemcpyHostToDevice, s));
+        }
+    }
+    HIP_TRY(env, hipStreamSynchronize(s));
+    if (!env_ids && n == d.B) env->loaded_slots |= 1u << slot;
+    else if (slot == 0 && env->loaded_slots == 0) env->loaded_slots |= 0;  // partial loads: caller's responsibility
+    return PCBENV_OK;
+}
+
+template <int KIND> static int launch_reset(pcbenv *env, const uint8_t *mask, hipStream_t s) {
+    const DevParams &d = env->dp;
+    if (d.WW == 1) hipLaunchKernelGGL((k_reset<KIND, 1>), dim3(d.B), dim3(WAVE), d.ldsBytes, s, d, mask);
+    else hipLaunchKernelGGL((k_reset<KIND, 2>), dim3(d.B), dim3(WAVE), d.ldsBytes, s, d, mask);
+    return 0;
+}
+template <int KIND> static int launch_step(pcbenv *env, const int *actions, int fmt, hipStream_t s) {
+    const DevParams &d = env->dp;
+    if (d.WW == 1) hipLaunchKernelGGL((k_step<KIND, 1>), dim3(d.B), dim3(WAVE), d.ldsBytes, s, d, actions, fmt);
+    else hipLaunchKernelGGL((k_step<KIND, 2>), dim3(d.B), dim3(WAVE), d.ldsBytes, s, d, actions, fmt);
+    return 0;
+}
+
+static int pre_launch(pcbenv *env) {
+    if (!env) return fail(0, PCBENV_EINVAL, "null handle");
+    if (!env->bound) return fail(env, PCBENV_ESTATE, "pcbenv_bind_buffers has not been called");
+    HIP_TRY(env, hipSetDevice(env->device));
+    return PCBENV_OK;
+}
+
+extern "C" int pcbenv_reset(pcbenv *env, const uint8_t *mask_dev, void *stream) {
+    int rc = pre_launch(env);
+    if (rc) return rc;
+    if (env->cfg.kind != PCBENV_SQUARE && !(env->loaded_slots & 1u))
+        return fail(env, PCBENV_ESTATE, "no instances loaded (pcbenv_load_instances slot 0 for all environments first)");
+    if (env->cfg.kind != PCBENV_SQUARE && env->loaded_slots != (env->dp.Q >= 32 ? ~0u : ((1u << env->dp.Q) - 1u)))
+        return fail(env, PCBENV_ESTATE, "every queue slot must be loaded before reset");
+    hipStream_t s = (hipStream_t)stream;
+    switch (env->cfg.kind) {
+    case PCBENV_SQUARE: launch_reset<PCBENV_SQUARE>(env, mask_dev, s); break;
+    case PCBENV_RECT: launch_reset<PCBENV_RECT>(env, mask_dev, s); break;
+    case PCBENV_PIN: launch_reset<PCBENV_PIN>(env, mask_dev, s); break;
+    default: launch_reset<PCBENV_SPATIAL>(env, mask_dev, s); break;
+    }
+    HIP_TRY(env, hipGetLastError());
+    return PCBENV_OK;
+}
+
+extern "C" int pcbenv_step(pcbenv *env, const int32_t *actions_dev, int32_t fmt, void *stream) {
+    int rc = pre_launch(env);
+    if (rc) return rc;
+    if (!actions_dev) return fail(env, PCBENV_EINVAL, "null actions");
+    if (fmt != PCBENV_ACTION_TUPLE && fmt != PCBENV_ACTION_FLAT) return fail(env, PCBENV_EINVAL, "unknown action format");
+    hipStream_t s = (hipStream_t)stream;
+    switch (env->cfg.kind) {
+    case PCBENV_SQUARE: launch_step<PCBENV_SQUARE>(env, actions_dev, fmt, s); break;
+    case PCBENV_RECT: launch_step<PCBENV_RECT>(env, actions_dev, fmt, s); break;
+    case PCBENV_PIN: launch_step<PCBENV_PIN>(env, actions_dev, fmt, s); break;
+    default: launch_step<PCBENV_SPATIAL>(env, actions_dev, fmt, s); break;
+    }
+    HIP_TRY(env, hipGetLastError());
+    return PCBENV_OK;
+}
+
+extern "C" int pcbenv_sample_actions(pcbenv *env, int32_t *actions_dev, int32_t fmt, uint64_t seed,
+                                     uint64_t first_env_index, uint64_t step_index, void *stream) {
+    if (!env || !actions_dev) return fail(env, PCBENV_EINVAL, "null argument");
+    if (fmt != PCBENV_ACTION_TUPLE && fmt != PCBENV_ACTION_FLAT) return fail(env, PCBENV_EINVAL, "unknown action format");
+    HIP_TRY(env, hipSetDevice(env->device));
+    hipLaunchKernelGGL(k_sample, dim3(env->dp.B), dim3(WAVE), 0, (hipStream_t)stream, env->dp, actions_dev, fmt,
+                       (u64)seed, (u64)first_env_index, (u64)step_index);
+    HIP_TRY(env, hipGetLastError());
+    return PCBENV_OK;
+}
+
+extern "C" const uint64_t *pcbenv_mask_bits(const pcbenv *env, int64_t *env_stride_bytes) {
+    if (!env) return 0;
+    if (env_stride_bytes) *env_stride_bytes = env->dp.stateStride;
+    return (const uint64_t *)(env->dp.state + env->dp.offVm);
+}

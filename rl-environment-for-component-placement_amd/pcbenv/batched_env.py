@@ -1,0 +1,183 @@
+"""BatchedPlacementEnv: thousands of independent placement environments on one MI355X.
+
+The host-side mirror of the reference `gym.Env` classes
+(`environment/dummy_env_{square,rectangular,rectangular_pin,rectangular_pin_spatial}.py`):
+same observation keys, same action encoding, `reset()` / `step()` with a leading
+batch dimension.  Observations are torch tensors that live on the device and are
+updated in place by every call (the reference returns fresh copies -- `.clone()`
+where copy semantics are needed).  All compute happens in libpcbenv.so's HIP
+kernels on the current torch stream; nothing here touches observation data.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import EnvConfig, KIND_PIN, KIND_RECT, KIND_SPATIAL, KIND_SQUARE
+from .instances import Instance, InstanceStream, env_seed, pack_instances
+
+
+def obs_spec(cfg: EnvConfig) -> Dict[str, tuple]:
+    """key -> (shape without batch dim, torch dtype); keys and shapes are the reference's."""
+    H, W, k = cfg.height, cfg.width, cfg.kind
+    u8, f64 = torch.uint8, torch.float64
+    if k == KIND_SQUARE:
+        return {"grid": ((H, W), u8), "action_mask": ((H, W), u8)}
+    Cc = cfg.max_num_components
+    if k == KIND_RECT:
+        return {"grid": ((H, W), u8), "action_mask": ((2, H, W), u8), "all_components_feature": ((Cc, 5), f64),
+                "component_mask": ((Cc,), f64), "placement_mask": ((Cc,), f64)}
+    mp, N = cfg.max_num_pins_per_component, cfg.max_num_nets
+    if k == KIND_PIN:
+        return {"grid": ((H, W), u8), "action_mask": ((4, H, W), u8), "all_components_feature": ((Cc, 5), f64),
+                "placement_mask": ((Cc,), f64), "all_pins_num_feature": ((Cc, mp, 4), f64),
+                "all_pins_cat_feature": ((Cc, mp, 1), f64)}
+    return {"grid": ((H, W), u8), "pin_grid": ((H, W, N + 1), u8),
+            "component_grid": ((Cc, cfg.max_component_h, cfg.max_component_w, N + 1), u8),
+            "action_mask": ((4, H, W), u8), "all_components_feature": ((Cc, 5 + mp), f64),
+            "placement_mask": ((Cc,), f64), "all_pins_num_feature": ((Cc * mp + 1, 4), f64),
+            "all_pins_cat_feature": ((Cc * mp + 1, 2), f64)}
+
+
+class BatchedPlacementEnv:
+    def __init__(self, cfg: EnvConfig, num_envs: int, device="cuda:0", queue_depth: int = 1,
+                 run_seed: int = 0, first_env_index: int = 0, incremental_obs: bool = False):
+        cfg.validate()
+        self.cfg, self.num_envs, self.queue_depth = cfg, int(num_envs), int(queue_depth)
+        self.run_seed, self.first_env_index = int(run_seed), int(first_env_index)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("BatchedPlacementEnv needs a GPU device (there is no CPU fallback)")
+        self._L = _lib.load()
+        self._ccfg = _lib.make_config(cfg, num_envs, queue_depth,
+                                      _lib.FLAG_INCREMENTAL_OBS if incremental_obs else 0)
+        h = C.c_void_p()
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        _lib.check(self._L.pcbenv_create(C.byref(self._ccfg), dev_index, C.byref(h)))
+        self._h = h
+        B = self.num_envs
+        with torch.cuda.device(self.device):
+            self.obs: Dict[str, torch.Tensor] = {
+                k: torch.zeros((B,) + shape, dtype=dt, device=self.device) for k, (shape, dt) in obs_spec(cfg).items()}
+            self.reward = torch.zeros(B, dtype=torch.float64, device=self.device)
+            self.done = torch.zeros(B, dtype=torch.uint8, device=self.device)
+            self.info_raw = torch.full((B, 2), float("nan"), dtype=torch.float64, device=self.device)
+            self._actions = torch.zeros((B, 3), dtype=torch.int32, device=self.device)
+        bufs = _lib.PcbenvBuffers()
+        for name in _lib.BUFFER_FIELDS:
+            t = self.obs.get(name)
+            if name == "reward":
+                t = self.reward
+            elif name == "done":
+                t = self.done
+            elif name == "info":
+                t = self.info_raw if cfg.kind in (KIND_PIN, KIND_SPATIAL) else None
+            setattr(bufs, name, t.data_ptr() if t is not None else None)
+        _lib.check(self._L.pcbenv_bind_buffers(self._h, C.byref(bufs)), self._h)
+        self._streams: Optional[List[InstanceStream]] = None
+        torch.cuda.synchronize(self.device)
+
+    # -- lifetime ---------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            torch.cuda.synchronize(self.device)
+            self._L.pcbenv_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # -- instances --------------------------------------------------------------------------
+    def load_instances(self, instances: Sequence[Instance], slot: int = 0, env_ids: Optional[Sequence[int]] = None):
+        """Queue one instance per environment (or per listed env id) into `slot`."""
+        if self.cfg.kind == KIND_SQUARE:
+            return
+        packed = np.ascontiguousarray(pack_instances(self.cfg, instances))
+        self.load_packed(packed, slot, env_ids)
+
+    def load_packed(self, packed: np.ndarray, slot: int = 0, env_ids: Optional[Sequence[int]] = None):
+        ids = None if env_ids is None else np.ascontiguousarray(env_ids, np.int32)
+        _lib.check(self._L.pcbenv_load_instances(
+            self._h, None if ids is None else ids.ctypes.data, packed.shape[0], slot, packed.ctypes.data,
+            self._stream()), self._h)
+
+    def generate_instances(self) -> List[List[Instance]]:
+        """Fill every queue slot from per-environment reference RNG streams (seed = f(run_seed, global env index)):
+        slot s holds each environment's s-th reset instance, exactly what the reference env seeded with that
+        stream seed would draw at its s-th `reset()`."""
+        if self.cfg.kind == KIND_SQUARE:
+            return []
+        if self._streams is None:
+            self._streams = [InstanceStream(self.cfg, env_seed(self.run_seed, self.first_env_index + i))
+                             for i in range(self.num_envs)]
+        out = []
+        for s in range(self.queue_depth):
+            inst = [st.next() for st in self._streams]
+            self.load_instances(inst, slot=s)
+            out.append(inst)
+        return out
+
+    # -- gym-style API ----------------------------------------------------------------------
+    def reset(self, mask: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        m = None
+        if mask is not None:
+            m = mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        _lib.check(self._L.pcbenv_reset(self._h, None if m is None else m.data_ptr(), self._stream()), self._h)
+        return self.obs
+
+    def reset_done(self) -> Dict[str, torch.Tensor]:
+        """Explicit auto-reset: environments whose last step returned done take their next instance."""
+        _lib.check(self._L.pcbenv_reset(self._h, self.done.data_ptr(), self._stream()), self._h)
+        return self.obs
+
+    def step(self, actions: torch.Tensor):
+        """actions: int tensor [B, 3] = (orientation, x, y) ([B, 2] = (x, y) for the square env) or flat [B]
+        (`a = o*H*W + x*W + y`, utils/environment/env_wrappers.py:80-98)."""
+        a = actions.to(device=self.device, dtype=torch.int32)
+        if a.dim() == 1:
+            fmt = _lib.ACTION_FLAT
+            a = a.contiguous()
+        else:
+            fmt = _lib.ACTION_TUPLE
+            if a.shape[1] == 2:
+                self._actions[:, 1:] = a
+                a = self._actions
+            a = a.contiguous()
+        assert a.shape[0] == self.num_envs
+        _lib.check(self._L.pcbenv_step(self._h, a.data_ptr(), fmt, self._stream()), self._h)
+        return self.obs, self.reward, self.done, self.info
+
+    @property
+    def info(self) -> Dict[str, torch.Tensor]:
+        """`wirelength` / `num_intersections` per environment; NaN where the reference's info dict is `{}`."""
+        if self.cfg.kind not in (KIND_PIN, KIND_SPATIAL):
+            return {}
+        return {"wirelength": self.info_raw[:, 0], "num_intersections": self.info_raw[:, 1]}
+
+    def sample_actions(self, step_index: int, flat: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Uniform draw over the legal actions of every environment, on device (random-policy counterpart)."""
+        if out is None:
+            out = torch.empty((self.num_envs,) if flat else (self.num_envs, 3), dtype=torch.int32, device=self.device)
+        _lib.check(self._L.pcbenv_sample_actions(
+            self._h, out.data_ptr(), _lib.ACTION_FLAT if flat else _lib.ACTION_TUPLE, self.run_seed,
+            self.first_env_index, int(step_index), self._stream()), self._h)
+        return out
+
+    # reference-style attribute access
+    @property
+    def action_mask(self) -> torch.Tensor:
+        return self.obs["action_mask"]
+
+    @property
+    def grid(self) -> torch.Tensor:
+        return self.obs["grid"]

@@ -1,0 +1,148 @@
+"""GPU parity: the HIP path (through the C ABI, via BatchedPlacementEnv) against
+(a) the golden episodes recorded from the reference and (b) the CPU oracle on
+device-sampled action streams.  Bit-exact: uint8 cells == reference 0/1,
+float64 features / reward / info identical bit patterns."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import case_names, load_case, pad_component_grid
+from pcbenv import EnvConfig, InstanceStream, env_seed, named_config, pack_instances
+from pcbenv.batched_env import BatchedPlacementEnv
+from pcbenv.config import KIND_PIN, KIND_SPATIAL, KIND_SQUARE
+
+pytestmark = pytest.mark.gpu
+
+BEAM_READY = False
+
+
+def _host(obs):
+    return {k: v.cpu().numpy() for k, v in obs.items()}
+
+
+def _same_bits(a, b):
+    a = np.ascontiguousarray(a, np.float64)
+    b = np.ascontiguousarray(b, np.float64)
+    return a.shape == b.shape and np.array_equal(a.view(np.uint64), b.view(np.uint64))
+
+
+@pytest.mark.parametrize("name", case_names())
+def test_golden_episodes_on_gpu(name):
+    meta, cfg, eps = load_case(name)
+    if cfg.kind in (KIND_PIN, KIND_SPATIAL) and cfg.reward_type != "centroid" and not BEAM_READY:
+        pytest.skip("beam routes not built yet")
+    B = len(eps)
+    env = BatchedPlacementEnv(cfg, B, queue_depth=1)
+    if cfg.kind != KIND_SQUARE:
+        env.load_instances([e.instance for e in eps])
+    obs = _host(env.reset())
+    for i, e in enumerate(eps):
+        for k, stack in e.obs.items():
+            want = stack[0] if k != "component_grid" else pad_component_grid(stack[0], cfg.max_num_components)
+            assert np.array_equal(obs[k][i].astype(np.float64), want), (name, i, k, "reset")
+    T = max(len(e.actions) for e in eps)
+    for t in range(T):
+        acts = np.zeros((B, 3), np.int32)
+        live = [t < len(e.actions) for e in eps]
+        for i, e in enumerate(eps):
+            if live[i]:
+                acts[i] = e.actions[t]
+        o, r, d, info = env.step(torch.from_numpy(acts))
+        obs = _host(o)
+        r = r.cpu().numpy(); d = d.cpu().numpy()
+        inf = env.info_raw.cpu().numpy()
+        for i, e in enumerate(eps):
+            if not live[i]:
+                continue
+            tag = (name, e.seed, e.ep, t, tuple(acts[i]))
+            for k, stack in e.obs.items():
+                want = stack[t + 1] if k != "component_grid" else pad_component_grid(stack[t + 1], cfg.max_num_components)
+                got = obs[k][i].astype(np.float64)
+                assert np.array_equal(got, want), (tag, k, np.argwhere(got != want)[:4])
+            assert np.float64(r[i]).tobytes() == np.float64(e.reward[t]).tobytes(), (tag, r[i], e.reward[t])
+            assert bool(d[i]) == bool(e.done[t]), tag
+            if cfg.kind in (KIND_PIN, KIND_SPATIAL):
+                if np.isnan(e.info[t, 0]):
+                    assert np.isnan(inf[i]).all(), tag
+                else:
+                    assert _same_bits(inf[i], e.info[t]), (tag, inf[i], e.info[t])
+    env.close()
+
+
+def _oracle_rollout(cfg, B, episodes, queue_depth=2, p_bad=0.02):
+    """Device-sampled legal actions (plus a few corrupted ones); every observation, reward, done, info of every step
+    must equal the CPU oracle's.  Covers reset_done() and the instance queue."""
+    from oracle import oracle as orc
+    env = BatchedPlacementEnv(cfg, B, queue_depth=queue_depth, run_seed=3)
+    inst = env.generate_instances()
+    ob = orc.OracleBatch(cfg, B)
+    packed = [pack_instances(cfg, s) for s in inst] if cfg.kind != KIND_SQUARE else None
+    cursor = np.zeros(B, np.int64)
+
+    def oracle_reset(mask):
+        if cfg.kind == KIND_SQUARE:
+            for i in np.flatnonzero(mask):
+                ob.env(i).reset()
+            return
+        rec = np.stack([packed[cursor[i] % queue_depth][i] for i in range(B)])
+        ob.reset_packed(rec, mask.astype(np.uint8))
+        cursor[mask.astype(bool)] += 1
+
+    env.reset()
+    oracle_reset(np.ones(B, np.uint8))
+    rng = np.random.RandomState(5)
+    steps = 0
+    done_eps = 0
+    t = 0
+    keys = list(env.obs.keys())
+    while done_eps < episodes * B and t < 400:
+        a = env.sample_actions(t).cpu().numpy()
+        bad = rng.rand(B) < p_bad
+        a[bad] = rng.randint(-1, 70, size=(int(bad.sum()), 3))
+        o, r, d, _ = env.step(torch.from_numpy(a))
+        rr, dd, ii = ob.step(a)
+        obs = _host(o)
+        r = r.cpu().numpy(); d = d.cpu().numpy(); inf = env.info_raw.cpu().numpy()
+        assert np.array_equal(d, dd), (t, np.flatnonzero(d != dd)[:5])
+        assert _same_bits(r, rr), (t, np.flatnonzero(r != rr)[:5], r[r != rr][:3], rr[r != rr][:3])
+        if cfg.kind in (KIND_PIN, KIND_SPATIAL):
+            has = ~np.isnan(inf[:, 0])
+            assert _same_bits(inf[has], ii[has]), t
+        for i in range(B):
+            want = ob.env(i).obs()
+            for k in keys:
+                assert np.array_equal(obs[k][i].astype(np.float64), want[k]), (t, i, k)
+        done_eps += int(d.sum())
+        env.reset_done()
+        oracle_reset(d)
+        steps += B
+        t += 1
+    env.close()
+    return steps
+
+
+def test_c1_square_vs_oracle():
+    _oracle_rollout(named_config("c1"), 8, episodes=3)
+
+
+def test_c2_rect_vs_oracle():
+    _oracle_rollout(named_config("c2"), 32, episodes=2)
+
+
+def test_c3_pin_vs_oracle():
+    _oracle_rollout(named_config("c3"), 32, episodes=2)
+
+
+def test_c4_spatial_vs_oracle():
+    _oracle_rollout(named_config("c4"), 16, episodes=2)
+
+
+def test_c5_spatial_128_vs_oracle():
+    _oracle_rollout(named_config("c5"), 4, episodes=1, queue_depth=1, p_bad=0.0)
+
+
+def test_small_odd_grids_vs_oracle():
+    _oracle_rollout(EnvConfig.spatial(10, 10, 3, 4, 2, 4, 2, 4, 6, 1, 2, 4, 5, 2, "centroid", 2, 0.5), 24, episodes=3, p_bad=0.05)
+    _oracle_rollout(EnvConfig.pin(12, 12, 5, 5, 2, 5, 2, 5, 8, 6, 3, 5, 7, 2, "centroid", 2, 0.25), 24, episodes=3, p_bad=0.05)
+    _oracle_rollout(EnvConfig.rect(6, 7, 2, 4, 2, 4, 4, 2), 16, episodes=3, p_bad=0.05)
+    _oracle_rollout(EnvConfig.square(11, 10, 2), 8, episodes=2, p_bad=0.05)

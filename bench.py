@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env-steps/s of the batched reset/step/mask/reward hot path.
+
+    python bench.py --gpus N --steps K --warmup W [--config c3] [--reward centroid] [--envs 4096]
+
+A "step" is one batched transition of all environments on a GPU: on-device uniform
+sampling of a legal action, `pcbenv_step` (place + legal mask + observations + the
+terminal routing reward), and the explicit `reset_done()` that follows every
+terminal transition (instances come from the per-environment queue in HBM, filled
+before the timed region from reference-exact RNG streams).  Environments shard by
+global index over ranks with no data-path collective (weak scaling).
+
+One JSON line on rank 0: metric/value (whole-job env-steps/s), `roofline` for the
+dominant kernel (k_step: algorithmic bytes per launch / mean launch duration from
+HIP events on the launch stream), and `cpu_baseline` (the oracle restatement of the
+reference, timed on this box's host cores over a bounded sample of the same
+instances and the same action stream, with a parity check of rewards/dones).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(REPO, "rl-environment-for-component-placement_amd"))
+sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def algorithmic_bytes_per_env_step(cfg) -> int:
+    """1 byte per cell for grid / action_mask / pin_grid, 8-byte table records."""
+    from pcbenv.config import KIND_SPATIAL
+    HW = cfg.height * cfg.width
+    b = HW + HW + cfg.num_orientations * HW
+    if cfg.kind == KIND_SPATIAL:
+        b += (cfg.max_num_nets + 1) * HW
+    b += 2 * 8 * (cfg.max_num_components + cfg.max_total_pins)
+    return b
+
+
+def cpu_baseline(cfg, run_seed, sample_envs, sample_steps, queue_depth):
+    """Time the CPU oracle (port of the reference) on a bounded sample; parity-check it against the GPU."""
+    from oracle import oracle as orc
+    from pcbenv import pack_instances
+    from pcbenv.batched_env import BatchedPlacementEnv
+    from pcbenv.config import KIND_SQUARE
+    env = BatchedPlacementEnv(cfg, sample_envs, queue_depth=queue_depth, run_seed=run_seed)
+    inst = env.generate_instances()
+    packed = [pack_instances(cfg, s) for s in inst] if cfg.kind != KIND_SQUARE else None
+    env.reset()
+    acts, dones, rewards = [], [], []
+    for t in range(sample_steps):  # record the action stream on the GPU
+        a = env.sample_actions(t)
+        _, r, d, _ = env.step(a)
+        acts.append(a.cpu().numpy().copy()); dones.append(d.cpu().numpy().copy()); rewards.append(r.cpu().numpy().copy())
+        env.reset_done()
+    env.close()
+    ob = orc.OracleBatch(cfg, sample_envs)
+    out = {}
+    # the GPU box gives one GPU's share of the host: 16 cores (do not oversubscribe the shared machine)
+    for threads in sorted({1, max(1, min(16, ob.max_threads, os.cpu_count() or 1))}):
+        cursor = np.zeros(sample_envs, np.int64)
+
+        def do_reset(mask):
+            if cfg.kind == KIND_SQUARE:
+                for i in np.flatnonzero(mask):
+                    ob.env(i).reset()
+                return
+            rec = np.stack([packed[cursor[i] % queue_depth][i] for i in range(sample_envs)])
+            ob.reset_packed(rec, mask.astype(np.uint8), threads)
+            cursor[mask.astype(bool)] += 1
+        do_reset(np.ones(sample_envs, np.uint8))
+        ok = True
+        t0 = time.perf_counter()
+        for t in range(sample_steps):
+            r, d, _ = ob.step(acts[t], threads)
+            ok &= bool(np.array_equal(d, dones[t]) and np.array_equal(r.view(np.uint64), rewards[t].view(np.uint64)))
+            do_reset(d)
+        dt = time.perf_counter() - t0
+        out[threads] = (sample_envs * sample_steps / dt, ok)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=320)
+    ap.add_argument("--warmup", type=int, default=32)
+    ap.add_argument("--config", default="c3", help="c2 | c3 | c4 | c5 (SURVEY.md §8)")
+    ap.add_argument("--reward", default="centroid", choices=["centroid", "beam", "both"])
+    ap.add_argument("--envs", type=int, default=0, help="environments per GPU (default: the config's batch)")
+    ap.add_argument("--queue-depth", type=int, default=2)
+    ap.add_argument("--run-seed", type=int, default=0)
+    ap.add_argument("--incremental", action="store_true", help="PCBENV_FLAG_INCREMENTAL_OBS")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from pcbenv import named_config
+    from pcbenv.batched_env import BatchedPlacementEnv
+    cfg = named_config(args.config, args.reward)
+    B = args.envs or {"c1": 1, "c2": 1024, "c3": 4096, "c4": 4096, "c5": 8192}[args.config]
+    env = BatchedPlacementEnv(cfg, B, device=f"cuda:{local_rank}", queue_depth=args.queue_depth,
+                              run_seed=args.run_seed, first_env_index=rank * B, incremental_obs=args.incremental)
+    t_gen = time.perf_counter()
+    env.generate_instances()
+    t_gen = time.perf_counter() - t_gen
+    env.reset()
+    actions = torch.empty((B, 3), dtype=torch.int32, device=env.device)
+
+    def one_step(t, ev=None):
+        env.sample_actions(t, out=actions)
+        if ev is not None:
+            ev[0].record()
+        env.step(actions)
+        if ev is not None:
+            ev[1].record()
+        env.reset_done()
+
+    for t in range(args.warmup):
+        one_step(t)
+    use_ev = not args.no_kernel_events
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)] if use_ev else None
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        one_step(args.warmup + k, events[k] if use_ev else None)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=env.device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    step_kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events])) if use_ev else None
+
+    if rank == 0:
+        b_alg = algorithmic_bytes_per_env_step(cfg)
+        value = world * B * args.steps / elapsed
+        roof = None
+        if step_kernel_ms:
+            achieved = b_alg * B / (step_kernel_ms * 1e-3) / 1e9
+            traffic = None
+            tpath = os.path.join(REPO, "profiles", f"traffic_{args.config}.json")
+            if os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            roof = {"bound": "hbm", "kernel": "k_step", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+                    "frac": round(achieved / 8000.0, 4), "traffic": traffic,
+                    "algorithmic_bytes_per_env_step": b_alg, "units_per_launch": B,
+                    "kernel_ms": round(step_kernel_ms, 5)}
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            sample_envs, sample_steps = {"c2": (4096, 128), "c3": (2048, 64), "c4": (2048, 48), "c5": (256, 64)}.get(args.config, (64, 64))
+            res = cpu_baseline(cfg, args.run_seed, sample_envs, sample_steps, args.queue_depth)
+            nthr = max(res)
+            cpu = {"value": round(res[nthr][0], 1), "unit": "env-steps/s", "cores": nthr, "kind": "port",
+                   "sample": f"{sample_envs} envs x {sample_steps} steps of the same instances and action stream (oracle/pcbenv_oracle.c, OpenMP)",
+                   "single_thread_value": round(res[1][0], 1), "parity_with_gpu": bool(all(v[1] for v in res.values()))}
+        line = {"metric": "env_steps_per_sec", "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u64 bit-rows + f64 reward",
+                "data": "synthetic (reference-exact instance generator, seeds 1000003*run_seed+env; uniform legal actions drawn on device)",
+                "config": {"workload": f"{args.config}: {cfg.height}x{cfg.width} grid, {cfg.max_num_components} components, "
+                                       f"{cfg.max_total_pins} pins, reward={args.reward}", "envs_per_gpu": B,
+                           "queue_depth": args.queue_depth, "incremental_obs": bool(args.incremental),
+                           "instance_generation_s": round(t_gen, 2)},
+                "roofline": roof, "cpu_baseline": cpu}
+        print(json.dumps(line), flush=True)
+    env.close()
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -174,55 +174,266 @@ __device__ inline bool is_intersect(double x1, double y1, double x2, double y2, 
            fmin(y1, y2) <= y && y <= fmax(y1, y2) && fmin(y3, y4) <= y && y <= fmax(y3, y4);
 }
 
-// Centroid routing + intersections + wirelength for one environment (S:1243-1271, :629-651, :704-722).
-// Segment q belongs to pin q: (pin q, centroid of its net); a 2-pin net has the single segment (p0, p1)
-// carried by its first pin.  seg layout in LDS: x1[P] y1[P] x2[P] y2[P] dist[P] then int active/net [P].
-__device__ inline void route_centroid(const DevParams &p, const EnvHdr *hdr, const PinRec *pins, double *seg,
-                                      int lane, double *wirelength, int *nintersections) {
-    const int P = p.P, np = hdr->npins, nn = hdr->nnets;
-    double *X1 = seg, *Y1 = seg + P, *X2 = seg + 2 * P, *Y2 = seg + 3 * P, *D = seg + 4 * P;
-    double *cen = seg + 5 * P;             // cx[MAX_NETS], cy[MAX_NETS]
-    int *act = (int *)(cen + 2 * PCBENV_MAX_NETS);  // 1 = carries a segment
-    int *nstart = act + P;                 // [nnets + 1]
+// ---- routes -------------------------------------------------------------------------------------
+// A route is kept as one segment slot per pin q (slots of net n are nstart[n]..nstart[n+1]-1, so slots are
+// net-major like the reference's route lists); act[q] = 1 if the slot carries a segment.
+struct SegView { double *X1, *Y1, *X2, *Y2, *D, *cen; int *act, *nstart, *pre; };
+#define SEG_LDS_BYTES(P) ((5 * (P) + 2 * PCBENV_MAX_NETS) * 8 + (2 * (P) + PCBENV_MAX_NETS + 4) * 4)
+__device__ inline SegView seg_view(double *seg, int P) {
+    SegView v;
+    v.X1 = seg; v.Y1 = seg + P; v.X2 = seg + 2 * P; v.Y2 = seg + 3 * P; v.D = seg + 4 * P;
+    v.cen = seg + 5 * P;                              // cx[MAX_NETS], cy[MAX_NETS]
+    v.act = (int *)(v.cen + 2 * PCBENV_MAX_NETS);     // [P]
+    v.nstart = v.act + P;                             // [nnets + 1]
+    v.pre = v.nstart + PCBENV_MAX_NETS + 2;           // [P + 1] prefix of pair counts
+    return v;
+}
+
+// net_pins offsets (self.pins is net-major) and S:1229-1241 get_centroid per net (exact integer sums, one division)
+__device__ inline void net_offsets_and_centroids(const SegView &v, const EnvHdr *hdr, const PinRec *pins, int lane) {
+    const int np = hdr->npins, nn = hdr->nnets;
     for (int q = lane; q < np; q += WAVE)
-        if (q == 0 || pins[q].net != pins[q - 1].net) nstart[pins[q].net] = q;
-    if (lane == 0) nstart[nn] = np;
+        if (q == 0 || pins[q].net != pins[q - 1].net) v.nstart[pins[q].net] = q;
+    if (lane == 0) v.nstart[nn] = np;
     __syncthreads();
-    for (int n = lane; n < nn; n += WAVE) {  // get_centroid: exact integer sums, one division each
-        int s = nstart[n], e = nstart[n + 1];
+    for (int n = lane; n < nn; n += WAVE) {
+        const int s = v.nstart[n], e = v.nstart[n + 1];
         double sx = 0, sy = 0;
         for (int q = s; q < e; q++) { sx += (double)pins[q].abs_x; sy += (double)pins[q].abs_y; }
-        cen[n] = sx / (double)(e - s);
-        cen[PCBENV_MAX_NETS + n] = sy / (double)(e - s);
+        v.cen[n] = sx / (double)(e - s);
+        v.cen[PCBENV_MAX_NETS + n] = sy / (double)(e - s);
     }
     __syncthreads();
+}
+
+// S:1243-1271 route_pins_centroid: (pin, centroid) per pin; a 2-pin net is the single segment (p0, p1)
+__device__ inline void build_centroid_segments(const SegView &v, const EnvHdr *hdr, const PinRec *pins, int lane) {
+    const int np = hdr->npins;
     for (int q = lane; q < np; q += WAVE) {
-        int n = pins[q].net, s = nstart[n], cnt = nstart[n + 1] - s;
+        const int n = pins[q].net, s = v.nstart[n], cnt = v.nstart[n + 1] - s;
         double x1 = pins[q].abs_x, y1 = pins[q].abs_y, x2, y2;
         int a = 1;
-        if (cnt == 2) {
-            a = (q == s);
-            x2 = pins[s + 1].abs_x; y2 = pins[s + 1].abs_y;
-        } else {
-            x2 = cen[n]; y2 = cen[PCBENV_MAX_NETS + n];
-        }
-        X1[q] = x1; Y1[q] = y1; X2[q] = x2; Y2[q] = y2; act[q] = a;
-        D[q] = norm2(x1 - x2, y1 - y2);
+        if (cnt == 2) { a = (q == s); x2 = pins[s + 1].abs_x; y2 = pins[s + 1].abs_y; }
+        else { x2 = v.cen[n]; y2 = v.cen[PCBENV_MAX_NETS + n]; }
+        v.X1[q] = x1; v.Y1[q] = y1; v.X2[q] = x2; v.Y2[q] = y2; v.act[q] = a;
+        v.D[q] = norm2(x1 - x2, y1 - y2);
     }
     __syncthreads();
+}
+
+// S:629-651 find_num_intersection + S:704-722 find_wirelength over the slots.  The (segment, later-net segment)
+// pairs are flattened over the 64 lanes; the wirelength is summed sequentially in route order (bit-exact).
+__device__ inline void count_and_length(const SegView &v, const EnvHdr *hdr, const PinRec *pins, int lane,
+                                        double *wirelength, int *nintersections) {
+    const int np = hdr->npins;
+    if (lane == 0) {
+        int acc = 0;
+        for (int i = 0; i < np; i++) { v.pre[i] = acc; if (v.act[i]) acc += np - v.nstart[pins[i].net + 1]; }
+        v.pre[np] = acc;
+    }
+    __syncthreads();
+    const int total = v.pre[np];
     int cnt = 0;
-    for (int i = 0; i < np; i++) {
-        if (!act[i]) continue;
-        const int ni = pins[i].net;
-        const double x1 = X1[i], y1 = Y1[i], x2 = X2[i], y2 = Y2[i];
-        for (int j = nstart[ni + 1] + lane; j < np; j += WAVE)  // segments of later nets only
-            if (act[j] && is_intersect(x1, y1, x2, y2, X1[j], Y1[j], X2[j], Y2[j])) cnt++;
+    for (int t = lane; t < total; t += WAVE) {
+        int lo = 0, hi = np;  // largest i with pre[i] <= t (and a non-empty range)
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (v.pre[mid] <= t) lo = mid; else hi = mid; }
+        const int i = lo, j = v.nstart[pins[i].net + 1] + (t - v.pre[i]);
+        if (v.act[j] && is_intersect(v.X1[i], v.Y1[i], v.X2[i], v.Y2[i], v.X1[j], v.Y1[j], v.X2[j], v.Y2[j])) cnt++;
     }
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
-    double wl = 0.0;  // sequential sum in route order (bit-exact with the reference's python float loop)
-    for (int q = 0; q < np; q++) if (act[q]) wl += D[q];
+    double wl = 0.0;
+    for (int q = 0; q < np; q++) if (v.act[q]) wl += v.D[q];
     *wirelength = wl;
     *nintersections = cnt;
+    __syncthreads();
+}
+
+__device__ inline void route_centroid(const DevParams &p, const EnvHdr *hdr, const PinRec *pins, double *seg,
+                                      int lane, double *wirelength, int *nintersections) {
+    const SegView v = seg_view(seg, p.P);
+    net_offsets_and_centroids(v, hdr, pins, lane);
+    build_centroid_segments(v, hdr, pins, lane);
+    count_and_length(v, hdr, pins, lane, wirelength, nintersections);
+}
+
+// ---- beam-search routing (S:1273-1286 pin_outlier, S:1303-1369 beam_search, S:1371-1406) -----------------
+// beam_search sorts `points_to_visit - visited` with a stable sort, so equal-distance neighbours keep the
+// iteration order of that temporary CPython set.  The order is a pure function of the tuple hashes and of
+// Objects/setobject.c's open-addressing table (SURVEY.md trap T2); modelled here for <= 15 points per net.
+#define CS_EMPTY 0xFF
+#define CS_DUMMY 0xFE
+#define BS_MAXPTS (PCBENV_MAX_PINS_PER_NET - 1)
+#define BS_MAXQ (PCBENV_MAX_BEAM_WIDTH * PCBENV_MAX_BEAM_WIDTH)
+struct CSet { int mask, fill, used; unsigned char t[32]; };
+
+__device__ inline u64 tuple_hash2(int x, int y) {  // Objects/tupleobject.c (xxHash-style), hash(int) == int
+    const u64 P1 = 11400714785074694791ull, P2 = 14029467366897019727ull, P5 = 2870177450012600261ull;
+    u64 acc = P5;
+    acc += (u64)(long long)x * P2; acc = (acc << 31) | (acc >> 33); acc *= P1;
+    acc += (u64)(long long)y * P2; acc = (acc << 31) | (acc >> 33); acc *= P1;
+    acc += 2ull ^ (P5 ^ 3527539ull);
+    return acc == ~0ull ? 1546275796ull : acc;
+}
+__device__ inline void cs_init(CSet &s, int size) {
+    s.mask = size - 1; s.fill = 0; s.used = 0;
+    for (int i = 0; i < 32; i++) s.t[i] = CS_EMPTY;
+}
+// first unused slot on the probe sequence of `hash` (set_insert_clean / the miss path of set_add_entry)
+__device__ inline int cs_probe_unused(const CSet &s, u64 hash, int *freeslot) {
+    const unsigned mask = (unsigned)s.mask;
+    u64 perturb = hash;
+    unsigned i = (unsigned)hash & mask;
+    for (;;) {
+        const unsigned probes = (i + 9u <= mask) ? 9u : 0u;
+        for (unsigned k = 0; k <= probes; k++) {
+            const unsigned char c = s.t[i + k];
+            if (c == CS_EMPTY) return (int)(i + k);
+            if (c == CS_DUMMY && freeslot) *freeslot = (int)(i + k);
+        }
+        perturb >>= 5;
+        i = (unsigned)(((u64)i * 5u + 1u + perturb) & mask);
+    }
+}
+__device__ inline void cs_resize(CSet &s, int minused, const signed char *px, const signed char *py) {
+    int newsize = 8;
+    while (newsize <= minused) newsize <<= 1;
+    CSet old = s;
+    cs_init(s, newsize);
+    for (int i = 0; i <= old.mask; i++)
+        if (old.t[i] < CS_DUMMY) s.t[cs_probe_unused(s, tuple_hash2(px[old.t[i]], py[old.t[i]]), 0)] = old.t[i];
+    s.fill = s.used = old.used;
+}
+__device__ inline void cs_add(CSet &s, int key, const signed char *px, const signed char *py) {
+    int freeslot = -1;
+    const int slot = cs_probe_unused(s, tuple_hash2(px[key], py[key]), &freeslot);
+    if (freeslot >= 0) { s.t[freeslot] = (unsigned char)key; s.used++; return; }
+    s.t[slot] = (unsigned char)key; s.fill++; s.used++;
+    if (s.fill * 5 >= s.mask * 3) cs_resize(s, s.used * 4, px, py);
+}
+__device__ inline void cs_discard(CSet &s, int key, const signed char *px, const signed char *py) {
+    const unsigned mask = (unsigned)s.mask;
+    const u64 hash = tuple_hash2(px[key], py[key]);
+    u64 perturb = hash;
+    unsigned i = (unsigned)hash & mask;
+    for (;;) {
+        const unsigned probes = (i + 9u <= mask) ? 9u : 0u;
+        for (unsigned k = 0; k <= probes; k++) {
+            const unsigned char c = s.t[i + k];
+            if (c == CS_EMPTY) return;
+            if (c == (unsigned char)key) { s.t[i + k] = CS_DUMMY; s.used--; return; }
+        }
+        perturb >>= 5;
+        i = (unsigned)(((u64)i * 5u + 1u + perturb) & mask);
+    }
+}
+// iteration order of `A - visited` (set_difference): copy-and-discard when len(A) >> 2 > len(visited)
+__device__ inline int cs_difference_order(const CSet &A, int m, unsigned visited, const signed char *px,
+                                          const signed char *py, unsigned char *order) {
+    CSet R;
+    if ((m >> 2) > __popc(visited)) {
+        cs_init(R, 8);
+        if (m * 5 >= R.mask * 3) { int ns = 8; while (ns <= 2 * m) ns <<= 1; cs_init(R, ns); }
+        if (R.mask == A.mask) { R = A; }  // set_merge: same size, no dummies -> the table is copied as is
+        else {
+            for (int i = 0; i <= A.mask; i++)
+                if (A.t[i] < CS_DUMMY) R.t[cs_probe_unused(R, tuple_hash2(px[A.t[i]], py[A.t[i]]), 0)] = A.t[i];
+            R.fill = R.used = A.used;
+        }
+        for (int k = 0; k < m; k++) if (visited >> k & 1u) cs_discard(R, k, px, py);
+        if (R.fill - R.used > R.mask / 4) cs_resize(R, R.used * 4, px, py);
+    } else {
+        cs_init(R, 8);
+        for (int i = 0; i <= A.mask; i++)
+            if (A.t[i] < CS_DUMMY && !(visited >> A.t[i] & 1u)) cs_add(R, A.t[i], px, py);
+    }
+    int n = 0;
+    for (int i = 0; i <= R.mask; i++) if (R.t[i] < CS_DUMMY) order[n++] = R.t[i];
+    return n;
+}
+
+struct BsEntry { double prio; unsigned visited; unsigned char len; unsigned char path[BS_MAXPTS + 1]; };  // path[0] = start (0xFF)
+
+// One net, one lane: fills the net's slots [s, s+cnt) of the segment view with the beam route.
+__device__ inline void beam_route_net(const SegView &v, const PinRec *pins, int s, int cnt, int k) {
+    signed char px[BS_MAXPTS + 1], py[BS_MAXPTS + 1];
+    const double cx = v.cen[pins[s].net], cy = v.cen[PCBENV_MAX_NETS + pins[s].net];
+    int st = 0; double bd = 0.0;  // pin_outlier: first arg-max of the distance to the centroid
+    for (int i = 0; i < cnt; i++) {
+        const double d = norm2((double)pins[s + i].abs_x - cx, (double)pins[s + i].abs_y - cy);
+        if (i == 0 || d > bd) { bd = d; st = i; }
+    }
+    const int sx = pins[s + st].abs_x, sy = pins[s + st].abs_y;
+    int m = 0;
+    for (int i = 0; i < cnt; i++) if (i != st) { px[m] = pins[s + i].abs_x; py[m] = pins[s + i].abs_y; m++; }
+    CSet A;
+    cs_init(A, 8);
+    for (int i = 0; i < m; i++) cs_add(A, i, px, py);
+    const unsigned all = (1u << m) - 1u;
+    BsEntry qa[BS_MAXQ], qb[BS_MAXQ];
+    BsEntry *queue = qa, *next = qb;
+    int qn = 1;
+    queue[0].prio = 0.0; queue[0].visited = 0; queue[0].len = 1; queue[0].path[0] = 0xFF;
+    const BsEntry *result = 0;
+    while (!result) {
+        int nn = 0;
+        unsigned taken = 0;
+        const int pops = k < qn ? k : qn;
+        for (int t = 0; t < pops && !result; t++) {
+            int best = -1;  // heappop: minimum (priority, path) of what is left
+            for (int i = 0; i < qn; i++) {
+                if (taken >> i & 1u) continue;
+                if (best < 0) { best = i; continue; }
+                const BsEntry &a = queue[i], &b = queue[best];
+                bool less;
+                if (a.prio != b.prio) less = a.prio < b.prio;
+                else {
+                    less = a.len < b.len;
+                    const int n = a.len < b.len ? a.len : b.len;
+                    for (int j = 0; j < n; j++) {
+                        const int ax = a.path[j] == 0xFF ? sx : px[a.path[j]], ay = a.path[j] == 0xFF ? sy : py[a.path[j]];
+                        const int bx = b.path[j] == 0xFF ? sx : px[b.path[j]], by = b.path[j] == 0xFF ? sy : py[b.path[j]];
+                        if (ax != bx) { less = ax < bx; break; }
+                        if (ay != by) { less = ay < by; break; }
+                    }
+                }
+                if (less) best = i;
+            }
+            taken |= 1u << best;
+            const BsEntry &e = queue[best];
+            if (e.visited == all) { result = &e; break; }
+            const int cur = e.path[e.len - 1];
+            const int ux = cur == 0xFF ? sx : px[cur], uy = cur == 0xFF ? sy : py[cur];
+            unsigned char order[BS_MAXPTS + 1];
+            double dist[BS_MAXPTS + 1];
+            const int cntn = cs_difference_order(A, m, e.visited, px, py, order);
+            for (int i = 0; i < cntn; i++) dist[i] = norm2((double)(ux - px[order[i]]), (double)(uy - py[order[i]]));
+            for (int i = 1; i < cntn; i++) {  // sorted(key=distance): stable
+                const unsigned char o = order[i]; const double d = dist[i];
+                int j = i - 1;
+                while (j >= 0 && dist[j] > d) { order[j + 1] = order[j]; dist[j + 1] = dist[j]; j--; }
+                order[j + 1] = o; dist[j + 1] = d;
+            }
+            const int take = cntn < k ? cntn : k;
+            for (int i = 0; i < take; i++) {
+                BsEntry &q = next[nn++];
+                q = e;
+                q.path[q.len++] = order[i];
+                q.visited |= 1u << order[i];
+                q.prio = e.prio + dist[i];
+            }
+        }
+        if (!result) { BsEntry *tmp = queue; queue = next; next = tmp; qn = nn; if (qn == 0) break; }
+    }
+    for (int i = 0; i < cnt; i++) v.act[s + i] = 0;
+    if (!result) return;
+    for (int i = 0; i + 1 < result->len; i++) {
+        const int a = result->path[i], b = result->path[i + 1];
+        const double x1 = a == 0xFF ? sx : px[a], y1 = a == 0xFF ? sy : py[a];
+        const double x2 = b == 0xFF ? sx : px[b], y2 = b == 0xFF ? sy : py[b];
+        v.X1[s + i] = x1; v.Y1[s + i] = y1; v.X2[s + i] = x2; v.Y2[s + i] = y2;
+        v.D[s + i] = norm2(x1 - x2, y1 - y2);
+        v.act[s + i] = 1;
+    }
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -598,6 +809,38 @@ __global__ __launch_bounds__(WAVE) void k_step(DevParams p, const int *__restric
 }
 
 // ----------------------------------------------------------------------------------------------
+// routed terminal reward for reward_type beam / both (S:866-886, :905-928); runs after k_step, only for
+// environments whose step left `pending` set (all components placed).  One lane per net for the beam search.
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WAVE) void k_reward_routes(DevParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int e = blockIdx.x, lane = threadIdx.x;
+    if (!p.pending[e]) return;
+    load_state(smem, p, e, lane);
+    Lds l = carve(smem, p);
+    const SegView v = seg_view(l.seg, p.P);
+    net_offsets_and_centroids(v, l.hdr, l.pins, lane);
+    for (int n = lane; n < l.hdr->nnets; n += WAVE)
+        beam_route_net(v, l.pins, v.nstart[n], v.nstart[n + 1] - v.nstart[n], p.beam_width);
+    __syncthreads();
+    double wsum; int cnt;
+    count_and_length(v, l.hdr, l.pins, lane, &wsum, &cnt);
+    if (p.reward_type == PCBENV_REWARD_BOTH) {  // S:609-627 lowest_num_intersections: ties keep the beam route
+        double wc; int kc;
+        build_centroid_segments(v, l.hdr, l.pins, lane);
+        count_and_length(v, l.hdr, l.pins, lane, &wc, &kc);
+        if (kc < cnt) { cnt = kc; wsum = wc; }
+    }
+    const double wl = wsum / p.wl_norm, ni = (double)cnt / p.int_norm;
+    const double reward = -1 * (p.w_wl * wl + p.w_int * ni);
+    if (lane == 0) {
+        p.buf.reward[e] = reward;
+        if (p.buf.info) { p.buf.info[2 * e] = wl; p.buf.info[2 * e + 1] = ni; }
+        p.pending[e] = 0;
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
 // uniform legal-action sampler (rollout driver; agent/random/random_policy_*.py counterpart)
 // ----------------------------------------------------------------------------------------------
 __device__ inline u64 mix64(u64 z) {  // splitmix64 finaliser
@@ -803,7 +1046,7 @@ extern "C" int pcbenv_create(const pcbenv_config *cfg, int device, pcbenv **out)
     d.ldsHf = (int)d.stateStride;
     d.ldsCls = d.ldsHf + d.H * d.WW * 8;
     d.ldsSeg = align16(d.ldsCls + (c.kind == PCBENV_SPATIAL ? d.H * d.W : 0));
-    d.ldsBytes = align16(d.ldsSeg + (is_pin_kind(c.kind) ? (5 * d.P + 2 * PCBENV_MAX_NETS) * 8 + (d.P + PCBENV_MAX_NETS + 2) * 4 : 0));
+    d.ldsBytes = align16(d.ldsSeg + (is_pin_kind(c.kind) ? SEG_LDS_BYTES(d.P) : 0));
     if (hipSetDevice(device) != hipSuccess) { int r = fail(0, PCBENV_EHIP, "hipSetDevice failed (no such device?)"); delete env; return r; }
     size_t sbytes = (size_t)d.stateStride * d.B, qbytes = (size_t)d.instStride * d.B * d.Q;
     if (hipMalloc((void **)&d.state, sbytes) != hipSuccess || hipMalloc((void **)&d.queue, qbytes ? qbytes : 16) != hipSuccess ||
@@ -934,6 +1177,8 @@ extern "C" int pcbenv_step(pcbenv *env, const int32_t *actions_dev, int32_t fmt,
     case PCBENV_PIN: launch_step<PCBENV_PIN>(env, actions_dev, fmt, s); break;
     default: launch_step<PCBENV_SPATIAL>(env, actions_dev, fmt, s); break;
     }
+    if (is_pin_kind(env->cfg.kind) && env->cfg.reward_type != PCBENV_REWARD_CENTROID)
+        hipLaunchKernelGGL(k_reward_routes, dim3(env->dp.B), dim3(WAVE), env->dp.ldsBytes, s, env->dp);
     HIP_TRY(env, hipGetLastError());
     return PCBENV_OK;
 }

@@ -13,7 +13,7 @@ from pcbenv.config import KIND_PIN, KIND_SPATIAL, KIND_SQUARE
 
 pytestmark = pytest.mark.gpu
 
-BEAM_READY = False
+BEAM_READY = True
 
 
 def _host(obs):
@@ -146,3 +146,10 @@ def test_small_odd_grids_vs_oracle():
     _oracle_rollout(EnvConfig.pin(12, 12, 5, 5, 2, 5, 2, 5, 8, 6, 3, 5, 7, 2, "centroid", 2, 0.25), 24, episodes=3, p_bad=0.05)
     _oracle_rollout(EnvConfig.rect(6, 7, 2, 4, 2, 4, 4, 2), 16, episodes=3, p_bad=0.05)
     _oracle_rollout(EnvConfig.square(11, 10, 2), 8, episodes=2, p_bad=0.05)
+
+
+def test_beam_and_both_rewards_vs_oracle():
+    for rt, k in (("beam", 2), ("both", 2), ("both", 3), ("beam", 4)):
+        _oracle_rollout(EnvConfig.pin(64, 64, 9, 9, 2, 6, 2, 6, 16, 16, 8, 8, 6, 6, rt, k, 0.5), 48, episodes=2, p_bad=0.0)
+    _oracle_rollout(EnvConfig.spatial(128, 128, 9, 9, 2, 8, 2, 8, 32, 32, 16, 16, 8, 8, "both", 3, 0.5), 6, episodes=1, queue_depth=1, p_bad=0.0)
+    _oracle_rollout(EnvConfig.spatial(24, 24, 5, 5, 2, 4, 2, 4, 12, 6, 2, 3, 16, 9, "both", 4, 0.5), 32, episodes=2, p_bad=0.02)

@@ -21,7 +21,8 @@
  *                          incl. validate_action, update_grid, place_component,
  *                          compute_action_mask, compute_if_done, find_reward
  *   action formats         utils/environment/env_wrappers.py:80-98, :184-199 (flat Discrete action)
- *   pcbenv_sample_actions  the uniform-random valid-action policy
+ *   pcbenv_sample_actions, pcbenv_step_sampled
+ *                          the uniform-random valid-action policy and its simulate() loop body
  *                            agent/random/random_policy_square.py:11-23 (and siblings)
  *
  * Observations are written into caller-owned device buffers (pcbenv_buffers)
@@ -72,8 +73,12 @@ enum pcbenv_action_format {
 };
 
 /* flags */
-#define PCBENV_FLAG_INCREMENTAL_OBS 1u /* grid / pin_grid: write only the cells a step changed (buffers must
-                                          not be modified by the caller between calls) */
+#define PCBENV_FLAG_INCREMENTAL_OBS 1u /* grid / pin_grid: a step writes only the rows it changed (the caller must
+                                          not modify those buffers between calls); action_mask is always whole */
+#define PCBENV_FLAG_AUTO_RESET 2u      /* a terminal transition is followed, inside the same pcbenv_step, by the
+                                          reset of that environment: reward / done / info describe the terminal
+                                          transition, the observation tensors already show the next episode
+                                          (vector-env convention).  Without it pcbenv_step never resets. */
 
 /* Constructor parameters: the reference constructors' arguments, same names. */
 typedef struct pcbenv_config {
@@ -161,6 +166,11 @@ int pcbenv_step(pcbenv *env, const int32_t *actions_dev, int32_t action_format, 
  * environments without a legal action get action 0. */
 int pcbenv_sample_actions(pcbenv *env, int32_t *actions_dev, int32_t action_format, uint64_t seed,
                           uint64_t first_env_index, uint64_t step_index, void *stream);
+
+/* pcbenv_sample_actions + pcbenv_step in one launch: draws the action exactly as pcbenv_sample_actions would,
+ * stores it in actions_out_dev (the trajectory record) and applies it. */
+int pcbenv_step_sampled(pcbenv *env, int32_t *actions_out_dev, int32_t action_format, uint64_t seed,
+                        uint64_t first_env_index, uint64_t step_index, void *stream);
 
 /* Bit-packed legal-action mask of the current component, library-owned device
  * memory: uint64 [B, 2, H, ceil(W/64)] (orientation 0/1; pin kinds: 2 = 0, 3 = 1;

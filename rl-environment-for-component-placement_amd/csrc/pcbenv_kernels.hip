@@ -109,17 +109,17 @@ __device__ inline uint4 expand16(unsigned bits) {
 }
 
 // Write one H x W uint8 plane (0/1) from bit rows in LDS: 16 bytes per lane, 1 KiB per wave instruction.
-template <int WW> __device__ inline void emit_plane(unsigned char *dst, const u64 *bits, int H, int W, int lane) {
-    const int cells = H * W;
+// Rows [r0, r1) only (full plane: 0, H).
+template <int WW> __device__ inline void emit_plane(unsigned char *dst, const u64 *bits, int r0, int r1, int W, int lane) {
     if ((W & 15) == 0 && (((uintptr_t)dst) & 15) == 0) {
         uint4 *d4 = (uint4 *)dst;
-        for (int c = lane; c < cells / 16; c += WAVE) {
+        for (int c = r0 * W / 16 + lane; c < r1 * W / 16; c += WAVE) {
             int cell = c * 16, r = cell / W, col = cell - r * W;
             unsigned b = (unsigned)(bits[r * WW + (col >> 6)] >> (col & 63)) & 0xFFFFu;
             d4[c] = expand16(b);
         }
     } else {  // odd widths (the reference's small test grids): byte path
-        for (int i = lane; i < cells; i += WAVE) {
+        for (int i = r0 * W + lane; i < r1 * W; i += WAVE) {
             int r = i / W, col = i - r * W;
             dst[i] = (unsigned char)((bits[r * WW + (col >> 6)] >> (col & 63)) & 1ull);
         }
@@ -492,51 +492,54 @@ template <int KIND, int WW> __device__ inline bool current_mask(const DevParams 
 }
 
 // grid + action_mask planes (+ pin_grid for the spatial kind) of environment e from LDS state.
-template <int KIND, int WW> __device__ inline void emit_cells(const DevParams &p, Lds &l, int e, int lane, bool with_grid) {
+// The grid is written for rows [gr0, gr1) only (the rows a step changed, or 0..H); the mask always in full.
+template <int KIND, int WW> __device__ inline void emit_cells(const DevParams &p, Lds &l, int e, int lane, int gr0, int gr1) {
     const int H = p.H, W = p.W, HW = H * W, plane = H * WW;
-    if (with_grid && p.buf.grid) emit_plane<WW>(p.buf.grid + (size_t)e * HW, l.occ, H, W, lane);
+    if (p.buf.grid) emit_plane<WW>(p.buf.grid + (size_t)e * HW, l.occ, gr0, gr1, W, lane);
     if (p.buf.action_mask) {
         unsigned char *m = p.buf.action_mask + (size_t)e * p.O * HW;
-        emit_plane<WW>(m, l.vm, H, W, lane);
-        if (KIND != PCBENV_SQUARE) emit_plane<WW>(m + HW, l.vm + plane, H, W, lane);
+        emit_plane<WW>(m, l.vm, 0, H, W, lane);
+        if (KIND != PCBENV_SQUARE) emit_plane<WW>(m + HW, l.vm + plane, 0, H, W, lane);
         if (KIND == PCBENV_PIN || KIND == PCBENV_SPATIAL) {  // S:1852-1853 mask[2] = mask[0], mask[3] = mask[1]
-            emit_plane<WW>(m + 2 * HW, l.vm, H, W, lane);
-            emit_plane<WW>(m + 3 * HW, l.vm + plane, H, W, lane);
+            emit_plane<WW>(m + 2 * HW, l.vm, 0, H, W, lane);
+            emit_plane<WW>(m + 3 * HW, l.vm + plane, 0, H, W, lane);
         }
     }
 }
 
-// S:1663-1675 draw_pins: class map (0 empty, 1 occupied without pin, n+2 pin of net n) -> one-hot[:, :, 1:]
-template <int WW> __device__ inline void emit_pin_grid(const DevParams &p, Lds &l, int e, int lane) {
+// S:1663-1675 draw_pins: class map (0 empty, 1 occupied without pin, n+2 pin of net n) -> one-hot[:, :, 1:];
+// rows [r0, r1) of the (H, W, K) tensor (a step only changes the rows of the placed rectangle).
+template <int WW> __device__ inline void emit_pin_grid(const DevParams &p, Lds &l, int e, int lane, int r0, int r1) {
     if (!p.buf.pin_grid) return;
-    const int H = p.H, W = p.W, HW = H * W, K = p.K;
-    for (int i = lane; i < HW; i += WAVE) {
+    const int W = p.W, HW = p.H * W, K = p.K;
+    const int c0 = r0 * W, c1 = r1 * W;
+    for (int i = c0 + lane; i < c1; i += WAVE) {
         int r = i / W, c = i - r * W;
         l.cls[i] = (unsigned char)((l.occ[r * WW + (c >> 6)] >> (c & 63)) & 1ull);
     }
     __syncthreads();
     for (int q = lane; q < l.hdr->npins; q += WAVE) {
         const PinRec pr = l.pins[q];
-        if (pr.abs_x >= 0 && pr.abs_y >= 0) l.cls[pr.abs_x * W + pr.abs_y] = (unsigned char)(pr.net + 2);
+        if (pr.abs_x >= r0 && pr.abs_x < r1 && pr.abs_y >= 0) l.cls[pr.abs_x * W + pr.abs_y] = (unsigned char)(pr.net + 2);
     }
     __syncthreads();
     unsigned char *dst = p.buf.pin_grid + (size_t)e * HW * K;
-    const long long bytes = (long long)HW * K;
-    if ((bytes & 15) == 0 && (((uintptr_t)dst) & 15) == 0) {
+    const long long b0 = (long long)c0 * K, b1 = (long long)c1 * K;
+    if ((b0 & 15) == 0 && (b1 & 15) == 0 && (((uintptr_t)dst) & 15) == 0) {
         uint4 *d4 = (uint4 *)dst;
-        for (int c = lane; c < (int)(bytes / 16); c += WAVE) {
-            int b0 = c * 16, cell = b0 / K, ch = b0 - cell * K;
+        for (int c = (int)(b0 / 16) + lane; c < (int)(b1 / 16); c += WAVE) {
+            int bb = c * 16, cell = bb / K, ch = bb - cell * K;
             unsigned w[4] = {0, 0, 0, 0};
             unsigned cl = l.cls[cell];
             #pragma unroll
             for (int k = 0; k < 16; k++) {
                 w[k >> 2] |= (unsigned)(cl == (unsigned)(ch + 1)) << (8 * (k & 3));
-                if (++ch == K) { ch = 0; cell++; cl = cell < HW ? l.cls[cell] : 0; }
+                if (++ch == K) { ch = 0; cell++; cl = cell < c1 ? l.cls[cell] : 0; }
             }
             d4[c] = make_uint4(w[0], w[1], w[2], w[3]);
         }
     } else {
-        for (long long i = lane; i < bytes; i += WAVE) {
+        for (long long i = b0 + lane; i < b1; i += WAVE) {
             int cell = (int)(i / K), ch = (int)(i - (long long)cell * K);
             dst[i] = (unsigned char)(l.cls[cell] == ch + 1);
         }
@@ -554,8 +557,9 @@ template <int KIND> __device__ inline void write_pin_num(const DevParams &p, int
 }
 
 // Terminal reward (S:793-929 find_reward).  beam / both routes are left to k_reward_routes.
+// Returns true when the routed reward is deferred to k_reward_routes (beam / both).
 template <int KIND>
-__device__ inline void terminal_reward(const DevParams &p, Lds &l, int e, int lane) {
+__device__ inline bool terminal_reward(const DevParams &p, Lds &l, int e, int lane) {
     const bool placed_all = l.hdr->cur < 0;
     double reward, wl, ni;
     if (!placed_all) {  // S:853-863 worst case: the upper bounds, normalised (spatial: twice, quirk Q3)
@@ -569,26 +573,80 @@ __device__ inline void terminal_reward(const DevParams &p, Lds &l, int e, int la
         reward = -1 * (p.w_wl * wl + p.w_int * ni);
     } else {
         if (lane == 0) p.pending[e] = 1;
-        return;
+        return true;
     }
     if (lane == 0) {
         p.buf.reward[e] = reward;
         if (p.buf.info) { p.buf.info[2 * e] = wl; p.buf.info[2 * e + 1] = ni; }
     }
+    return false;
 }
 
 // ----------------------------------------------------------------------------------------------
-// reset kernel (R:310-351, P:1544-1597, S:1487-1549, Q:74-113)
+// uniform legal-action sampler (rollout driver; agent/random/random_policy_*.py counterpart)
 // ----------------------------------------------------------------------------------------------
-template <int KIND, int WW>
-__global__ __launch_bounds__(WAVE) void k_reset(DevParams p, const unsigned char *__restrict__ mask) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ inline u64 mix64(u64 z) {  // splitmix64 finaliser
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ inline int select_bit(u64 w, int k) {  // position of the k-th (0-based) set bit
+    for (int i = 0; i < k; i++) w &= w - 1;
+    return __ffsll((long long)w) - 1;
+}
+// Uniform draw over the set bits of the legal-action bit mask vm (planes 0/1; pin kinds also mirror them as
+// orientations 2/3): per-lane popcounts, wave prefix sum, owner lane selects the k-th set bit.
+__device__ inline void sample_action(const u64 *vm, const DevParams &p, int genv, int lane, u64 seed, u64 step_index,
+                                     int *o, int *x, int *y) {
+    const int WW = p.WW, plane = p.H * WW;
+    const int words = (p.kind == PCBENV_SQUARE ? 1 : 2) * plane;
+    const int per = (words + WAVE - 1) / WAVE;
+    int mine = 0;
+    for (int i = lane * per; i < (lane + 1) * per && i < words; i++) mine += __popcll(vm[i]);
+    int incl = mine;
+    for (int d = 1; d < WAVE; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+    const int total = __shfl(incl, WAVE - 1);
+    *o = 0; *x = 0; *y = 0;
+    if (total <= 0) return;
+    const u64 rnd = mix64(mix64(seed ^ 0x9E3779B97F4A7C15ull * ((u64)genv + 1)) + step_index);
+    const int reps = (p.kind == PCBENV_PIN || p.kind == PCBENV_SPATIAL) ? 2 : 1;
+    const unsigned pick = (unsigned)(((rnd >> 32) * (u64)(total * reps)) >> 32);
+    const int k = (int)(pick % (unsigned)total), rep = (int)(pick / (unsigned)total);
+    const int excl = incl - mine;
+    const bool owner = k >= excl && k < incl;
+    int found = -1;
+    if (owner) {
+        int rem = k - excl;
+        for (int i = lane * per; i < (lane + 1) * per && i < words; i++) {
+            const int c = __popcll(vm[i]);
+            if (rem < c) { found = i * 64 + select_bit(vm[i], rem); break; }
+            rem -= c;
+        }
+    }
+    const u64 ball = __ballot(owner);
+    found = __shfl(found, __ffsll((long long)ball) - 1);
+    const int word = found >> 6, bit = found & 63;
+    const int pl = word / plane, rw = word - pl * plane;
+    *o = pl + 2 * rep; *x = rw / WW; *y = (rw - *x * WW) * 64 + bit;
+}
+__global__ __launch_bounds__(WAVE) void k_sample(DevParams p, int *__restrict__ actions, int fmt, u64 seed,
+                                                 u64 first_env, u64 step_index) {
     const int e = blockIdx.x, lane = threadIdx.x;
-    if (mask && !mask[e]) return;
-    Lds l = carve(smem, p);
+    const u64 *vm = (const u64 *)(p.state + (size_t)e * p.stateStride + p.offVm);
+    int o, x, y;
+    sample_action(vm, p, (int)first_env + e, lane, seed, step_index, &o, &x, &y);
+    if (lane == 0) {
+        if (fmt == PCBENV_ACTION_FLAT) actions[e] = o * p.H * p.W + x * p.W + y;
+        else { actions[3 * e] = o; actions[3 * e + 1] = x; actions[3 * e + 2] = y; }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// reset (R:310-351, P:1544-1597, S:1487-1549, Q:74-113): header is in LDS; builds the new episode's state in
+// LDS from the next queued instance and rewrites every observation tensor of environment e.
+// ----------------------------------------------------------------------------------------------
+template <int KIND, int WW> __device__ inline void reset_env(const DevParams &p, Lds &l, int e, int lane) {
     const int H = p.H, W = p.W, HW = H * W;
-    // header first (cursor / episode survive a reset)
-    if (lane == 0) *l.hdr = *(const EnvHdr *)(p.state + (size_t)e * p.stateStride);
     __syncthreads();
     for (int i = lane; i < H * WW; i += WAVE) l.occ[i] = 0ull;
     if (KIND != PCBENV_SQUARE) {
@@ -628,7 +686,7 @@ __global__ __launch_bounds__(WAVE) void k_reset(DevParams p, const unsigned char
     }
     __syncthreads();
     current_mask<KIND, WW>(p, l, lane);
-    emit_cells<KIND, WW>(p, l, e, lane, true);
+    emit_cells<KIND, WW>(p, l, e, lane, 0, H);
 
     if (KIND != PCBENV_SQUARE) {
         const int nc = l.hdr->ncomp, np = l.hdr->npins;
@@ -636,7 +694,7 @@ __global__ __launch_bounds__(WAVE) void k_reset(DevParams p, const unsigned char
         if (p.buf.all_components_feature) {
             double *cf = p.buf.all_components_feature + (size_t)e * p.C * p.F;
             for (int i = lane; i < p.C * p.F; i += WAVE) {
-                int c = i / p.F, k = i - c * p.F;
+                const int c = i / p.F, k = i - c * p.F;
                 double v = 0.0;
                 if (c < nc) {
                     const CompRec cr = l.comps[c];
@@ -694,7 +752,7 @@ __global__ __launch_bounds__(WAVE) void k_reset(DevParams p, const unsigned char
                 const int cgsz = p.mh * p.mw * p.K;
                 unsigned char *cg = p.buf.component_grid + (size_t)e * p.C * cgsz;
                 for (int i = lane; i < p.C * cgsz; i += WAVE) {
-                    int c = i / cgsz, k = i % p.K;
+                    const int c = i / cgsz, k = i % p.K;
                     cg[i] = (unsigned char)(c < nc && k == 0);
                 }
                 __syncthreads();
@@ -706,6 +764,17 @@ __global__ __launch_bounds__(WAVE) void k_reset(DevParams p, const unsigned char
             }
         }
     }
+    __syncthreads();
+}
+
+template <int KIND, int WW>
+__global__ __launch_bounds__(WAVE) void k_reset(DevParams p, const unsigned char *__restrict__ mask) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int e = blockIdx.x, lane = threadIdx.x;
+    if (mask && !mask[e]) return;
+    Lds l = carve(smem, p);
+    if (lane == 0) *l.hdr = *(const EnvHdr *)(p.state + (size_t)e * p.stateStride);  // cursor / episode survive
+    reset_env<KIND, WW>(p, l, e, lane);
     if (lane == 0) {
         p.buf.reward[e] = 0.0;
         p.buf.done[e] = 0;
@@ -717,17 +786,27 @@ __global__ __launch_bounds__(WAVE) void k_reset(DevParams p, const unsigned char
 
 // ----------------------------------------------------------------------------------------------
 // step kernel (R:353-432, P:1599-1710, S:1551-1661, Q:115-153)
+//   sampled != 0: the action is drawn here (same generator as k_sample) and written to `actions`
+//   PCBENV_FLAG_AUTO_RESET: a terminal transition is followed, in the same launch, by the reset
 // ----------------------------------------------------------------------------------------------
 template <int KIND, int WW>
-__global__ __launch_bounds__(WAVE) void k_step(DevParams p, const int *__restrict__ actions, int fmt) {
+__global__ __launch_bounds__(WAVE) void k_step(DevParams p, int *__restrict__ actions, int fmt, int sampled,
+                                               u64 seed, u64 first_env, u64 step_index) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int e = blockIdx.x, lane = threadIdx.x;
     const int H = p.H, W = p.W, HW = H * W, plane = H * WW;
     load_state(smem, p, e, lane);
     Lds l = carve(smem, p);
+    const bool auto_reset = p.flags & PCBENV_FLAG_AUTO_RESET;
 
     int o, x, y;
-    if (fmt == PCBENV_ACTION_FLAT) {  // utils/environment/env_wrappers.py:80-98, :184-199
+    if (sampled) {
+        sample_action(l.vm, p, (int)first_env + e, lane, seed, step_index, &o, &x, &y);
+        if (lane == 0) {
+            if (fmt == PCBENV_ACTION_FLAT) actions[e] = o * HW + x * W + y;
+            else { actions[3 * e] = o; actions[3 * e + 1] = x; actions[3 * e + 2] = y; }
+        }
+    } else if (fmt == PCBENV_ACTION_FLAT) {  // utils/environment/env_wrappers.py:80-98, :184-199
         const int a = actions[e];
         if (a < 0 || a >= p.O * HW) { o = -1; x = y = 0; }
         else { o = a / HW; const int r = a - o * HW; x = r / W; y = r - x * W; }
@@ -744,10 +823,12 @@ __global__ __launch_bounds__(WAVE) void k_step(DevParams p, const int *__restric
     if (lane == 0 && p.pending) p.pending[e] = 0;
     __syncthreads();
 
+    bool deferred = false;
     if (!valid) {  // terminal transition, state and observations unchanged (quirk Q8 iii)
         if (lane == 0) p.buf.done[e] = 1;
         if (KIND == PCBENV_SQUARE || KIND == PCBENV_RECT) { if (lane == 0) p.buf.reward[e] = 0.0; }
-        else terminal_reward<KIND>(p, l, e, lane);
+        else deferred = terminal_reward<KIND>(p, l, e, lane);
+        if (auto_reset && !deferred) { reset_env<KIND, WW>(p, l, e, lane); store_state(smem, p, e, lane); }
         return;
     }
 
@@ -797,14 +878,20 @@ __global__ __launch_bounds__(WAVE) void k_step(DevParams p, const int *__restric
     }
     __syncthreads();
     const bool any = current_mask<KIND, WW>(p, l, lane);
-    emit_cells<KIND, WW>(p, l, e, lane, true);
-    if (KIND == PCBENV_SPATIAL) emit_pin_grid<WW>(p, l, e, lane);
-
     const bool done = KIND == PCBENV_SQUARE ? !any : (l.hdr->cur < 0 || !any);  // S:1856-1869
     if (lane == 0) p.buf.done[e] = done ? 1 : 0;
     if (KIND == PCBENV_SQUARE || KIND == PCBENV_RECT) { if (lane == 0) p.buf.reward[e] = 1.0; }
     else if (!done) { if (lane == 0) p.buf.reward[e] = 0.0; }
-    else terminal_reward<KIND>(p, l, e, lane);
+    else deferred = terminal_reward<KIND>(p, l, e, lane);
+
+    if (done && auto_reset && !deferred) {
+        reset_env<KIND, WW>(p, l, e, lane);  // rewrites every observation: skip the terminal ones
+    } else {
+        const bool inc = (p.flags & PCBENV_FLAG_INCREMENTAL_OBS) != 0;
+        const int r0 = inc ? x : 0, r1 = inc ? min(x + ph, H) : H;
+        emit_cells<KIND, WW>(p, l, e, lane, r0, r1);
+        if (KIND == PCBENV_SPATIAL) emit_pin_grid<WW>(p, l, e, lane, r0, r1);
+    }
     store_state(smem, p, e, lane);
 }
 
@@ -812,6 +899,7 @@ __global__ __launch_bounds__(WAVE) void k_step(DevParams p, const int *__restric
 // routed terminal reward for reward_type beam / both (S:866-886, :905-928); runs after k_step, only for
 // environments whose step left `pending` set (all components placed).  One lane per net for the beam search.
 // ----------------------------------------------------------------------------------------------
+template <int KIND, int WW>
 __global__ __launch_bounds__(WAVE) void k_reward_routes(DevParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int e = blockIdx.x, lane = threadIdx.x;
@@ -838,62 +926,7 @@ __global__ __launch_bounds__(WAVE) void k_reward_routes(DevParams p) {
         if (p.buf.info) { p.buf.info[2 * e] = wl; p.buf.info[2 * e + 1] = ni; }
         p.pending[e] = 0;
     }
-}
-
-// ----------------------------------------------------------------------------------------------
-// uniform legal-action sampler (rollout driver; agent/random/random_policy_*.py counterpart)
-// ----------------------------------------------------------------------------------------------
-__device__ inline u64 mix64(u64 z) {  // splitmix64 finaliser
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
-__device__ inline int select_bit(u64 w, int k) {  // position of the k-th (0-based) set bit
-    for (int i = 0; i < k; i++) w &= w - 1;
-    return __ffsll((long long)w) - 1;
-}
-__global__ __launch_bounds__(WAVE) void k_sample(DevParams p, int *__restrict__ actions, int fmt, u64 seed,
-                                                 u64 first_env, u64 step_index) {
-    const int e = blockIdx.x, lane = threadIdx.x;
-    const int H = p.H, WW = p.WW, HW = H * p.W, plane = H * WW;
-    const u64 *vm = (const u64 *)(p.state + (size_t)e * p.stateStride + p.offVm);
-    const int nplanes = p.kind == PCBENV_SQUARE ? 1 : 2;
-    const int words = nplanes * plane;
-    // per-lane popcount over a contiguous chunk of words, then wave prefix sum
-    const int per = (words + WAVE - 1) / WAVE;
-    int mine = 0;
-    for (int i = lane * per; i < (lane + 1) * per && i < words; i++) mine += __popcll(vm[i]);
-    int incl = mine;
-    for (int d = 1; d < WAVE; d <<= 1) { int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
-    const int total = __shfl(incl, WAVE - 1);
-    int o = 0, x = 0, y = 0;
-    if (total > 0) {
-        const u64 rnd = mix64(mix64(seed ^ 0x9E3779B97F4A7C15ull * (first_env + (u64)e + 1)) + step_index);
-        const int reps = (p.kind == PCBENV_PIN || p.kind == PCBENV_SPATIAL) ? 2 : 1;  // orientations 2, 3 mirror 0, 1
-        const unsigned pick = (unsigned)(((rnd >> 32) * (u64)(total * reps)) >> 32);
-        const int k = (int)(pick % (unsigned)total), rep = (int)(pick / (unsigned)total);
-        const int excl = incl - mine;
-        const bool owner = k >= excl && k < incl;
-        int found = -1;
-        if (owner) {
-            int rem = k - excl;
-            for (int i = lane * per; i < (lane + 1) * per && i < words; i++) {
-                int c = __popcll(vm[i]);
-                if (rem < c) { found = i * 64 + select_bit(vm[i], rem); break; }
-                rem -= c;
-            }
-        }
-        const u64 ball = __ballot(owner);
-        const int src = __ffsll((long long)ball) - 1;
-        found = __shfl(found, src);
-        const int word = found >> 6, bit = found & 63;
-        const int pl = word / plane, rw = word - pl * plane;
-        o = pl + 2 * rep; x = rw / WW; y = (rw - x * WW) * 64 + bit;
-    }
-    if (lane == 0) {
-        if (fmt == PCBENV_ACTION_FLAT) actions[e] = o * HW + x * p.W + y;
-        else { actions[3 * e] = o; actions[3 * e + 1] = x; actions[3 * e + 2] = y; }
-    }
+    if (p.flags & PCBENV_FLAG_AUTO_RESET) { reset_env<KIND, WW>(p, l, e, lane); store_state(smem, p, e, lane); }
 }
 
 // ==============================================================================================
@@ -1133,11 +1166,24 @@ template <int KIND> static int launch_reset(pcbenv *env, const uint8_t *mask, hi
     else hipLaunchKernelGGL((k_reset<KIND, 2>), dim3(d.B), dim3(WAVE), d.ldsBytes, s, d, mask);
     return 0;
 }
-template <int KIND> static int launch_step(pcbenv *env, const int *actions, int fmt, hipStream_t s) {
+template <int KIND> static int launch_step(pcbenv *env, int *actions, int fmt, int sampled, u64 seed, u64 first_env,
+                                           u64 step_index, hipStream_t s) {
     const DevParams &d = env->dp;
-    if (d.WW == 1) hipLaunchKernelGGL((k_step<KIND, 1>), dim3(d.B), dim3(WAVE), d.ldsBytes, s, d, actions, fmt);
-    else hipLaunchKernelGGL((k_step<KIND, 2>), dim3(d.B), dim3(WAVE), d.ldsBytes, s, d, actions, fmt);
+    if (d.WW == 1) hipLaunchKernelGGL((k_step<KIND, 1>), dim3(d.B), dim3(WAVE), d.ldsBytes, s, d, actions, fmt, sampled, seed, first_env, step_index);
+    else hipLaunchKernelGGL((k_step<KIND, 2>), dim3(d.B), dim3(WAVE), d.ldsBytes, s, d, actions, fmt, sampled, seed, first_env, step_index);
+    if ((KIND == PCBENV_PIN || KIND == PCBENV_SPATIAL) && env->cfg.reward_type != PCBENV_REWARD_CENTROID) {
+        if (d.WW == 1) hipLaunchKernelGGL((k_reward_routes<KIND, 1>), dim3(d.B), dim3(WAVE), d.ldsBytes, s, d);
+        else hipLaunchKernelGGL((k_reward_routes<KIND, 2>), dim3(d.B), dim3(WAVE), d.ldsBytes, s, d);
+    }
     return 0;
+}
+static int dispatch_step(pcbenv *env, int *actions, int fmt, int sampled, u64 seed, u64 first_env, u64 step_index, hipStream_t s) {
+    switch (env->cfg.kind) {
+    case PCBENV_SQUARE: return launch_step<PCBENV_SQUARE>(env, actions, fmt, sampled, seed, first_env, step_index, s);
+    case PCBENV_RECT: return launch_step<PCBENV_RECT>(env, actions, fmt, sampled, seed, first_env, step_index, s);
+    case PCBENV_PIN: return launch_step<PCBENV_PIN>(env, actions, fmt, sampled, seed, first_env, step_index, s);
+    default: return launch_step<PCBENV_SPATIAL>(env, actions, fmt, sampled, seed, first_env, step_index, s);
+    }
 }
 
 static int pre_launch(pcbenv *env) {
@@ -1147,13 +1193,12 @@ static int pre_launch(pcbenv *env) {
     return PCBENV_OK;
 }
 
+static int check_queue(pcbenv *env);
 extern "C" int pcbenv_reset(pcbenv *env, const uint8_t *mask_dev, void *stream) {
     int rc = pre_launch(env);
     if (rc) return rc;
-    if (env->cfg.kind != PCBENV_SQUARE && !(env->loaded_slots & 1u))
-        return fail(env, PCBENV_ESTATE, "no instances loaded (pcbenv_load_instances slot 0 for all environments first)");
-    if (env->cfg.kind != PCBENV_SQUARE && env->loaded_slots != (env->dp.Q >= 32 ? ~0u : ((1u << env->dp.Q) - 1u)))
-        return fail(env, PCBENV_ESTATE, "every queue slot must be loaded before reset");
+    rc = check_queue(env);
+    if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     switch (env->cfg.kind) {
     case PCBENV_SQUARE: launch_reset<PCBENV_SQUARE>(env, mask_dev, s); break;
@@ -1165,20 +1210,29 @@ extern "C" int pcbenv_reset(pcbenv *env, const uint8_t *mask_dev, void *stream) 
     return PCBENV_OK;
 }
 
+static int check_queue(pcbenv *env) {
+    if (env->cfg.kind != PCBENV_SQUARE && env->loaded_slots != (env->dp.Q >= 32 ? ~0u : ((1u << env->dp.Q) - 1u)))
+        return fail(env, PCBENV_ESTATE, "every queue slot must be loaded (pcbenv_load_instances for all environments) first");
+    return PCBENV_OK;
+}
+
 extern "C" int pcbenv_step(pcbenv *env, const int32_t *actions_dev, int32_t fmt, void *stream) {
     int rc = pre_launch(env);
     if (rc) return rc;
     if (!actions_dev) return fail(env, PCBENV_EINVAL, "null actions");
     if (fmt != PCBENV_ACTION_TUPLE && fmt != PCBENV_ACTION_FLAT) return fail(env, PCBENV_EINVAL, "unknown action format");
-    hipStream_t s = (hipStream_t)stream;
-    switch (env->cfg.kind) {
-    case PCBENV_SQUARE: launch_step<PCBENV_SQUARE>(env, actions_dev, fmt, s); break;
-    case PCBENV_RECT: launch_step<PCBENV_RECT>(env, actions_dev, fmt, s); break;
-    case PCBENV_PIN: launch_step<PCBENV_PIN>(env, actions_dev, fmt, s); break;
-    default: launch_step<PCBENV_SPATIAL>(env, actions_dev, fmt, s); break;
-    }
-    if (is_pin_kind(env->cfg.kind) && env->cfg.reward_type != PCBENV_REWARD_CENTROID)
-        hipLaunchKernelGGL(k_reward_routes, dim3(env->dp.B), dim3(WAVE), env->dp.ldsBytes, s, env->dp);
+    dispatch_step(env, (int *)actions_dev, fmt, 0, 0, 0, 0, (hipStream_t)stream);
+    HIP_TRY(env, hipGetLastError());
+    return PCBENV_OK;
+}
+
+extern "C" int pcbenv_step_sampled(pcbenv *env, int32_t *actions_out_dev, int32_t fmt, uint64_t seed,
+                                   uint64_t first_env_index, uint64_t step_index, void *stream) {
+    int rc = pre_launch(env);
+    if (rc) return rc;
+    if (!actions_out_dev) return fail(env, PCBENV_EINVAL, "null actions");
+    if (fmt != PCBENV_ACTION_TUPLE && fmt != PCBENV_ACTION_FLAT) return fail(env, PCBENV_EINVAL, "unknown action format");
+    dispatch_step(env, actions_out_dev, fmt, 1, seed, first_env_index, step_index, (hipStream_t)stream);
     HIP_TRY(env, hipGetLastError());
     return PCBENV_OK;
 }

@@ -11,11 +11,12 @@ LIB_PATH = os.path.join(_PKG, "libpcbenv.so")
 PCBENV_OK, PCBENV_EINVAL, PCBENV_ELIMIT, PCBENV_EHIP, PCBENV_ESTATE = 0, -1, -2, -3, -4
 ACTION_TUPLE, ACTION_FLAT = 0, 1
 FLAG_INCREMENTAL_OBS = 1
+FLAG_AUTO_RESET = 2
 ABI_VERSION = 1
 
 EXPORTS = ("pcbenv_abi_version", "pcbenv_create", "pcbenv_destroy", "pcbenv_last_error",
            "pcbenv_instance_stride", "pcbenv_max_total_pins", "pcbenv_bind_buffers",
-           "pcbenv_load_instances", "pcbenv_reset", "pcbenv_step", "pcbenv_sample_actions",
+           "pcbenv_load_instances", "pcbenv_reset", "pcbenv_step", "pcbenv_sample_actions", "pcbenv_step_sampled",
            "pcbenv_mask_bits")
 
 
@@ -64,6 +65,7 @@ def load():
     L.pcbenv_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.pcbenv_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     L.pcbenv_sample_actions.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]
+    L.pcbenv_step_sampled.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]
     L.pcbenv_mask_bits.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
     L.pcbenv_mask_bits.restype = C.c_void_p
     if L.pcbenv_abi_version() != ABI_VERSION:

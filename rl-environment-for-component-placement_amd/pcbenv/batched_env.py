@@ -45,7 +45,8 @@ def obs_spec(cfg: EnvConfig) -> Dict[str, tuple]:
 
 class BatchedPlacementEnv:
     def __init__(self, cfg: EnvConfig, num_envs: int, device="cuda:0", queue_depth: int = 1,
-                 run_seed: int = 0, first_env_index: int = 0, incremental_obs: bool = False):
+                 run_seed: int = 0, first_env_index: int = 0, incremental_obs: bool = False,
+                 auto_reset: bool = False):
         cfg.validate()
         self.cfg, self.num_envs, self.queue_depth = cfg, int(num_envs), int(queue_depth)
         self.run_seed, self.first_env_index = int(run_seed), int(first_env_index)
@@ -53,8 +54,10 @@ class BatchedPlacementEnv:
         if self.device.type != "cuda":
             raise RuntimeError("BatchedPlacementEnv needs a GPU device (there is no CPU fallback)")
         self._L = _lib.load()
+        self.auto_reset = bool(auto_reset)
         self._ccfg = _lib.make_config(cfg, num_envs, queue_depth,
-                                      _lib.FLAG_INCREMENTAL_OBS if incremental_obs else 0)
+                                      (_lib.FLAG_INCREMENTAL_OBS if incremental_obs else 0)
+                                      | (_lib.FLAG_AUTO_RESET if auto_reset else 0))
         h = C.c_void_p()
         dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         _lib.check(self._L.pcbenv_create(C.byref(self._ccfg), dev_index, C.byref(h)))
@@ -172,6 +175,16 @@ class BatchedPlacementEnv:
             self._h, out.data_ptr(), _lib.ACTION_FLAT if flat else _lib.ACTION_TUPLE, self.run_seed,
             self.first_env_index, int(step_index), self._stream()), self._h)
         return out
+
+    def rollout_step(self, step_index: int, flat: bool = False, out: Optional[torch.Tensor] = None):
+        """`sample_actions` + `step` in one kernel launch (the body of the reference's random-policy
+        `simulate()` loop, agent/random/random_policy_square.py:38-56); `out` receives the actions taken."""
+        if out is None:
+            out = torch.empty((self.num_envs,) if flat else (self.num_envs, 3), dtype=torch.int32, device=self.device)
+        _lib.check(self._L.pcbenv_step_sampled(
+            self._h, out.data_ptr(), _lib.ACTION_FLAT if flat else _lib.ACTION_TUPLE, self.run_seed,
+            self.first_env_index, int(step_index), self._stream()), self._h)
+        return self.obs, self.reward, self.done, self.info, out
 
     # reference-style attribute access
     @property

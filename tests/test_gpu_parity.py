@@ -69,11 +69,12 @@ def test_golden_episodes_on_gpu(name):
     env.close()
 
 
-def _oracle_rollout(cfg, B, episodes, queue_depth=2, p_bad=0.02):
+def _oracle_rollout(cfg, B, episodes, queue_depth=2, p_bad=0.02, incremental=False, auto_reset=False, fused=False):
     """Device-sampled legal actions (plus a few corrupted ones); every observation, reward, done, info of every step
     must equal the CPU oracle's.  Covers reset_done() and the instance queue."""
     from oracle import oracle as orc
-    env = BatchedPlacementEnv(cfg, B, queue_depth=queue_depth, run_seed=3)
+    env = BatchedPlacementEnv(cfg, B, queue_depth=queue_depth, run_seed=3, incremental_obs=incremental,
+                              auto_reset=auto_reset)
     inst = env.generate_instances()
     ob = orc.OracleBatch(cfg, B)
     packed = [pack_instances(cfg, s) for s in inst] if cfg.kind != KIND_SQUARE else None
@@ -96,11 +97,19 @@ def _oracle_rollout(cfg, B, episodes, queue_depth=2, p_bad=0.02):
     t = 0
     keys = list(env.obs.keys())
     while done_eps < episodes * B and t < 400:
-        a = env.sample_actions(t).cpu().numpy()
-        bad = rng.rand(B) < p_bad
-        a[bad] = rng.randint(-1, 70, size=(int(bad.sum()), 3))
-        o, r, d, _ = env.step(torch.from_numpy(a))
+        if fused:
+            sampled = env.sample_actions(t).cpu().numpy()  # must equal what the fused launch draws
+            o, r, d, _, a_dev = env.rollout_step(t)
+            a = a_dev.cpu().numpy()
+            assert np.array_equal(a, sampled), t
+        else:
+            a = env.sample_actions(t).cpu().numpy()
+            bad = rng.rand(B) < p_bad
+            a[bad] = rng.randint(-1, 70, size=(int(bad.sum()), 3))
+            o, r, d, _ = env.step(torch.from_numpy(a))
         rr, dd, ii = ob.step(a)
+        if auto_reset:  # observations already show the next episode of the environments that finished
+            oracle_reset(dd)
         obs = _host(o)
         r = r.cpu().numpy(); d = d.cpu().numpy(); inf = env.info_raw.cpu().numpy()
         assert np.array_equal(d, dd), (t, np.flatnonzero(d != dd)[:5])
@@ -113,8 +122,9 @@ def _oracle_rollout(cfg, B, episodes, queue_depth=2, p_bad=0.02):
             for k in keys:
                 assert np.array_equal(obs[k][i].astype(np.float64), want[k]), (t, i, k)
         done_eps += int(d.sum())
-        env.reset_done()
-        oracle_reset(d)
+        if not auto_reset:
+            env.reset_done()
+            oracle_reset(d)
         steps += B
         t += 1
     env.close()
@@ -153,3 +163,20 @@ def test_beam_and_both_rewards_vs_oracle():
         _oracle_rollout(EnvConfig.pin(64, 64, 9, 9, 2, 6, 2, 6, 16, 16, 8, 8, 6, 6, rt, k, 0.5), 48, episodes=2, p_bad=0.0)
     _oracle_rollout(EnvConfig.spatial(128, 128, 9, 9, 2, 8, 2, 8, 32, 32, 16, 16, 8, 8, "both", 3, 0.5), 6, episodes=1, queue_depth=1, p_bad=0.0)
     _oracle_rollout(EnvConfig.spatial(24, 24, 5, 5, 2, 4, 2, 4, 12, 6, 2, 3, 16, 9, "both", 4, 0.5), 32, episodes=2, p_bad=0.02)
+
+
+@pytest.mark.parametrize("name", ["c2", "c3", "c4"])
+def test_incremental_obs_mode(name):
+    _oracle_rollout(named_config(name), 24, episodes=2, incremental=True)
+
+
+@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c4"])
+def test_auto_reset_and_fused_sampling(name):
+    _oracle_rollout(named_config(name), 24, episodes=3, auto_reset=True)
+    _oracle_rollout(named_config(name), 24, episodes=3, auto_reset=True, fused=True, incremental=True)
+    _oracle_rollout(named_config(name), 24, episodes=2, fused=True)
+
+
+def test_auto_reset_with_beam_routes():
+    _oracle_rollout(named_config("c4", "both"), 16, episodes=3, auto_reset=True, fused=True)
+    _oracle_rollout(EnvConfig.pin(12, 12, 5, 5, 2, 5, 2, 5, 8, 6, 3, 5, 7, 2, "beam", 2, 0.25), 24, episodes=3, p_bad=0.05, auto_reset=True)

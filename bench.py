@@ -95,6 +95,11 @@ def main():
     ap.add_argument("--queue-depth", type=int, default=2)
     ap.add_argument("--run-seed", type=int, default=0)
     ap.add_argument("--incremental", action="store_true", help="PCBENV_FLAG_INCREMENTAL_OBS")
+    ap.add_argument("--loop", default="fused", choices=["fused", "explicit"],
+                    help="fused: one launch per step (pcbenv_step_sampled + PCBENV_FLAG_AUTO_RESET); "
+                         "explicit: sample_actions, step, reset_done as three launches (reference-style loop)")
+    ap.add_argument("--threads-per-env", type=int, default=0)
+    ap.add_argument("--event-steps", type=int, default=128, help="extra steps timed per kernel launch with HIP events")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     args = ap.parse_args()
@@ -115,7 +120,8 @@ def main():
     cfg = named_config(args.config, args.reward)
     B = args.envs or {"c1": 1, "c2": 1024, "c3": 4096, "c4": 4096, "c5": 8192}[args.config]
     env = BatchedPlacementEnv(cfg, B, device=f"cuda:{local_rank}", queue_depth=args.queue_depth,
-                              run_seed=args.run_seed, first_env_index=rank * B, incremental_obs=args.incremental)
+                              run_seed=args.run_seed, first_env_index=rank * B, incremental_obs=args.incremental,
+                              auto_reset=(args.loop == "fused"), threads_per_env=args.threads_per_env)
     t_gen = time.perf_counter()
     env.generate_instances()
     t_gen = time.perf_counter() - t_gen
@@ -123,6 +129,13 @@ def main():
     actions = torch.empty((B, 3), dtype=torch.int32, device=env.device)
 
     def one_step(t, ev=None):
+        if args.loop == "fused":
+            if ev is not None:
+                ev[0].record()
+            env.rollout_step(t, out=actions)
+            if ev is not None:
+                ev[1].record()
+            return
         env.sample_actions(t, out=actions)
         if ev is not None:
             ev[0].record()
@@ -133,14 +146,19 @@ def main():
 
     for t in range(args.warmup):
         one_step(t)
-    use_ev = not args.no_kernel_events
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)] if use_ev else None
+    # HIP events on torch's current stream (= the stream every kernel is launched on).  In the fused loop a
+    # step IS one k_step launch, so one event pair around the timed region gives the mean launch duration with
+    # no per-launch event overhead; in the explicit loop a pair brackets each k_step launch (this costs ~5 us
+    # per event and is therefore done in a second, untimed-for-`value` pass).
+    ev_region = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     t0 = time.perf_counter()
+    ev_region[0].record()
     for k in range(args.steps):
-        one_step(args.warmup + k, events[k] if use_ev else None)
+        one_step(args.warmup + k)
+    ev_region[1].record()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -149,7 +167,16 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=env.device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    step_kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events])) if use_ev else None
+    step_kernel_ms = None
+    if not args.no_kernel_events:
+        if args.loop == "fused" and cfg.reward_type == "centroid":
+            step_kernel_ms = ev_region[0].elapsed_time(ev_region[1]) / args.steps
+        elif args.event_steps > 0:
+            events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.event_steps)]
+            for k in range(args.event_steps):
+                one_step(args.warmup + args.steps + k, events[k])
+            torch.cuda.synchronize()
+            step_kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
 
     if rank == 0:
         b_alg = algorithmic_bytes_per_env_step(cfg)
@@ -182,7 +209,7 @@ def main():
                 "data": "synthetic (reference-exact instance generator, seeds 1000003*run_seed+env; uniform legal actions drawn on device)",
                 "config": {"workload": f"{args.config}: {cfg.height}x{cfg.width} grid, {cfg.max_num_components} components, "
                                        f"{cfg.max_total_pins} pins, reward={args.reward}", "envs_per_gpu": B,
-                           "queue_depth": args.queue_depth, "incremental_obs": bool(args.incremental),
+                           "queue_depth": args.queue_depth, "incremental_obs": bool(args.incremental), "loop": args.loop,
                            "instance_generation_s": round(t_gen, 2)},
                 "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(line), flush=True)

@@ -24,6 +24,8 @@
 typedef unsigned long long u64;
 
 #define WAVE 64
+#define NT ((int)blockDim.x)   // threads per environment: 64 (one wave) or 256 (four waves, large grids)
+#define MAX_NT 256
 #define HDR_BYTES 32
 
 // ----------------------------------------------------------------------------------------------
@@ -47,7 +49,7 @@ struct __attribute__((aligned(16))) EnvHdr {
     short ncomp, nnets, npins, cur;  // cur = index of the current component, -1 = sentinel (all placed)
     unsigned episode;                // completed resets
     unsigned qcursor;                // next queue slot
-    unsigned loaded;                 // bit s set = queue slot s holds an instance
+    unsigned flag;                   // LDS scratch word for workgroup-wide any()
     unsigned pad[3];
 };
 static_assert(sizeof(EnvHdr) == HDR_BYTES, "header size");
@@ -57,6 +59,27 @@ struct CompRec { unsigned char h, w; signed char px, py; unsigned char pad[4]; }
 struct PinRec { unsigned char rel_x, rel_y; signed char abs_x, abs_y; unsigned char net, comp; unsigned short id; };
 #define PIN_ID_MASK 0x7FFF
 #define PIN_LOSER 0x8000  // pin env quirk Q1: a later pin of the same component shares this feature row
+
+// Workgroup barrier that waits for LDS traffic only.  __syncthreads() also drains the global stores in flight
+// (s_waitcnt vmcnt(0)), which would serialise the observation write stream between kernel phases.
+__device__ inline void lds_sync() {
+#ifdef PCBENV_FULL_SYNC
+    __syncthreads();
+    return;
+#endif
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+// any() over the workgroup; `flag` is an LDS word
+__device__ inline bool block_any(bool v, unsigned *flag) {
+    if (NT == WAVE) return __any(v);
+    if (threadIdx.x == 0) *flag = 0;
+    lds_sync();
+    if (__any(v) && (threadIdx.x & 63) == 0) *flag = 1;
+    lds_sync();
+    return *flag != 0;
+}
 
 // ----------------------------------------------------------------------------------------------
 // bit rows
@@ -113,13 +136,14 @@ __device__ inline uint4 expand16(unsigned bits) {
 template <int WW> __device__ inline void emit_plane(unsigned char *dst, const u64 *bits, int r0, int r1, int W, int lane) {
     if ((W & 15) == 0 && (((uintptr_t)dst) & 15) == 0) {
         uint4 *d4 = (uint4 *)dst;
-        for (int c = r0 * W / 16 + lane; c < r1 * W / 16; c += WAVE) {
-            int cell = c * 16, r = cell / W, col = cell - r * W;
+        const int sh = (W & (W - 1)) == 0 ? __ffs(W) - 1 : -1;
+        for (int c = r0 * W / 16 + lane; c < r1 * W / 16; c += NT) {
+            int cell = c * 16, r = sh >= 0 ? cell >> sh : cell / W, col = cell - r * W;
             unsigned b = (unsigned)(bits[r * WW + (col >> 6)] >> (col & 63)) & 0xFFFFu;
             d4[c] = expand16(b);
         }
     } else {  // odd widths (the reference's small test grids): byte path
-        for (int i = r0 * W + lane; i < r1 * W; i += WAVE) {
+        for (int i = r0 * W + lane; i < r1 * W; i += NT) {
             int r = i / W, col = i - r * W;
             dst[i] = (unsigned char)((bits[r * WW + (col >> 6)] >> (col & 63)) & 1ull);
         }
@@ -128,9 +152,9 @@ template <int WW> __device__ inline void emit_plane(unsigned char *dst, const u6
 __device__ inline void emit_zero(unsigned char *dst, long long bytes, int lane) {
     if ((bytes & 15) == 0 && (((uintptr_t)dst) & 15) == 0) {
         uint4 *d4 = (uint4 *)dst;
-        for (long long c = lane; c < bytes / 16; c += WAVE) d4[c] = make_uint4(0, 0, 0, 0);
+        for (long long c = lane; c < bytes / 16; c += NT) d4[c] = make_uint4(0, 0, 0, 0);
     } else {
-        for (long long i = lane; i < bytes; i += WAVE) dst[i] = 0;
+        for (long long i = lane; i < bytes; i += NT) dst[i] = 0;
     }
 }
 
@@ -138,11 +162,11 @@ __device__ inline void emit_zero(unsigned char *dst, long long bytes, int lane) 
 // vm[r] bit j = 1 iff r <= H-ph and j <= W-pw and occ[r..r+ph-1][j..j+pw-1] is empty.
 // Returns (wave-uniform) whether any bit is set.
 template <int WW>
-__device__ inline bool window_mask(const u64 *occ, u64 *hf, u64 *vm, int H, int W, int ph, int pw, int lane) {
-    for (int r = lane; r < H; r += WAVE) hfold<WW>(Row<WW>::load(occ + r * WW), pw).store(hf + r * WW);
-    __syncthreads();
+__device__ inline bool window_mask(const u64 *occ, u64 *hf, u64 *vm, int H, int W, int ph, int pw, int lane, unsigned *flag) {
+    for (int r = lane; r < H; r += NT) hfold<WW>(Row<WW>::load(occ + r * WW), pw).store(hf + r * WW);
+    lds_sync();
     bool any = false;
-    for (int r = lane; r < H; r += WAVE) {
+    for (int r = lane; r < H; r += NT) {
         Row<WW> v = Row<WW>::zero();
         if (r + ph <= H) {
             Row<WW> acc = Row<WW>::load(hf + r * WW);
@@ -152,8 +176,7 @@ __device__ inline bool window_mask(const u64 *occ, u64 *hf, u64 *vm, int H, int 
         v.store(vm + r * WW);
         any |= v.any();
     }
-    __syncthreads();
-    return __any(any);
+    return block_any(any, flag);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -192,24 +215,24 @@ __device__ inline SegView seg_view(double *seg, int P) {
 // net_pins offsets (self.pins is net-major) and S:1229-1241 get_centroid per net (exact integer sums, one division)
 __device__ inline void net_offsets_and_centroids(const SegView &v, const EnvHdr *hdr, const PinRec *pins, int lane) {
     const int np = hdr->npins, nn = hdr->nnets;
-    for (int q = lane; q < np; q += WAVE)
+    for (int q = lane; q < np; q += NT)
         if (q == 0 || pins[q].net != pins[q - 1].net) v.nstart[pins[q].net] = q;
     if (lane == 0) v.nstart[nn] = np;
-    __syncthreads();
-    for (int n = lane; n < nn; n += WAVE) {
+    lds_sync();
+    for (int n = lane; n < nn; n += NT) {
         const int s = v.nstart[n], e = v.nstart[n + 1];
         double sx = 0, sy = 0;
         for (int q = s; q < e; q++) { sx += (double)pins[q].abs_x; sy += (double)pins[q].abs_y; }
         v.cen[n] = sx / (double)(e - s);
         v.cen[PCBENV_MAX_NETS + n] = sy / (double)(e - s);
     }
-    __syncthreads();
+    lds_sync();
 }
 
 // S:1243-1271 route_pins_centroid: (pin, centroid) per pin; a 2-pin net is the single segment (p0, p1)
 __device__ inline void build_centroid_segments(const SegView &v, const EnvHdr *hdr, const PinRec *pins, int lane) {
     const int np = hdr->npins;
-    for (int q = lane; q < np; q += WAVE) {
+    for (int q = lane; q < np; q += NT) {
         const int n = pins[q].net, s = v.nstart[n], cnt = v.nstart[n + 1] - s;
         double x1 = pins[q].abs_x, y1 = pins[q].abs_y, x2, y2;
         int a = 1;
@@ -218,7 +241,7 @@ __device__ inline void build_centroid_segments(const SegView &v, const EnvHdr *h
         v.X1[q] = x1; v.Y1[q] = y1; v.X2[q] = x2; v.Y2[q] = y2; v.act[q] = a;
         v.D[q] = norm2(x1 - x2, y1 - y2);
     }
-    __syncthreads();
+    lds_sync();
 }
 
 // S:629-651 find_num_intersection + S:704-722 find_wirelength over the slots.  The (segment, later-net segment)
@@ -226,26 +249,30 @@ __device__ inline void build_centroid_segments(const SegView &v, const EnvHdr *h
 __device__ inline void count_and_length(const SegView &v, const EnvHdr *hdr, const PinRec *pins, int lane,
                                         double *wirelength, int *nintersections) {
     const int np = hdr->npins;
+    int *total_cnt = v.nstart + PCBENV_MAX_NETS + 1;  // spare slot behind nstart[0..MAX_NETS]
     if (lane == 0) {
         int acc = 0;
         for (int i = 0; i < np; i++) { v.pre[i] = acc; if (v.act[i]) acc += np - v.nstart[pins[i].net + 1]; }
         v.pre[np] = acc;
+        *total_cnt = 0;
     }
-    __syncthreads();
+    lds_sync();
     const int total = v.pre[np];
     int cnt = 0;
-    for (int t = lane; t < total; t += WAVE) {
+    for (int t = lane; t < total; t += NT) {
         int lo = 0, hi = np;  // largest i with pre[i] <= t (and a non-empty range)
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (v.pre[mid] <= t) lo = mid; else hi = mid; }
         const int i = lo, j = v.nstart[pins[i].net + 1] + (t - v.pre[i]);
         if (v.act[j] && is_intersect(v.X1[i], v.Y1[i], v.X2[i], v.Y2[i], v.X1[j], v.Y1[j], v.X2[j], v.Y2[j])) cnt++;
     }
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if ((lane & 63) == 0 && cnt) atomicAdd(total_cnt, cnt);
+    lds_sync();
     double wl = 0.0;
     for (int q = 0; q < np; q++) if (v.act[q]) wl += v.D[q];
     *wirelength = wl;
-    *nintersections = cnt;
-    __syncthreads();
+    *nintersections = *total_cnt;
+    lds_sync();
 }
 
 __device__ inline void route_centroid(const DevParams &p, const EnvHdr *hdr, const PinRec *pins, double *seg,
@@ -458,14 +485,14 @@ __device__ inline Lds carve(unsigned char *smem, const DevParams &p) {
 __device__ inline void load_state(unsigned char *smem, const DevParams &p, int e, int lane) {
     const uint4 *src = (const uint4 *)(p.state + (size_t)e * p.stateStride);
     uint4 *dst = (uint4 *)smem;
-    for (int i = lane; i < (int)(p.stateStride / 16); i += WAVE) dst[i] = src[i];
-    __syncthreads();
+    for (int i = lane; i < (int)(p.stateStride / 16); i += NT) dst[i] = src[i];
+    lds_sync();
 }
 __device__ inline void store_state(const unsigned char *smem, const DevParams &p, int e, int lane) {
-    __syncthreads();
+    lds_sync();
     uint4 *dst = (uint4 *)(p.state + (size_t)e * p.stateStride);
     const uint4 *src = (const uint4 *)smem;
-    for (int i = lane; i < (int)(p.stateStride / 16); i += WAVE) dst[i] = src[i];
+    for (int i = lane; i < (int)(p.stateStride / 16); i += NT) dst[i] = src[i];
 }
 
 // Mask of the current component (or zeros) into l.vm, both orientations.  Returns "some action is legal".
@@ -474,19 +501,19 @@ template <int KIND, int WW> __device__ inline bool current_mask(const DevParams 
     const int cur = l.hdr->cur;
     bool any = false;
     if (KIND == PCBENV_SQUARE) {
-        any = window_mask<WW>(l.occ, l.hf, l.vm, H, W, p.component_n, p.component_n, lane);
+        any = window_mask<WW>(l.occ, l.hf, l.vm, H, W, p.component_n, p.component_n, lane, &l.hdr->flag);
     } else if (cur >= 0) {
         const int h = l.comps[cur].h, w = l.comps[cur].w;
-        any = window_mask<WW>(l.occ, l.hf, l.vm, H, W, h, w, lane);
+        any = window_mask<WW>(l.occ, l.hf, l.vm, H, W, h, w, lane, &l.hdr->flag);
         if (h == w) {
-            for (int i = lane; i < plane; i += WAVE) l.vm[plane + i] = l.vm[i];
-            __syncthreads();
+            for (int i = lane; i < plane; i += NT) l.vm[plane + i] = l.vm[i];
+            lds_sync();
         } else {
-            any |= window_mask<WW>(l.occ, l.hf, l.vm + plane, H, W, w, h, lane);
+            any |= window_mask<WW>(l.occ, l.hf, l.vm + plane, H, W, w, h, lane, &l.hdr->flag);
         }
     } else {
-        for (int i = lane; i < 2 * plane; i += WAVE) l.vm[i] = 0ull;
-        __syncthreads();
+        for (int i = lane; i < 2 * plane; i += NT) l.vm[i] = 0ull;
+        lds_sync();
     }
     return any;
 }
@@ -513,33 +540,39 @@ template <int WW> __device__ inline void emit_pin_grid(const DevParams &p, Lds &
     if (!p.buf.pin_grid) return;
     const int W = p.W, HW = p.H * W, K = p.K;
     const int c0 = r0 * W, c1 = r1 * W;
-    for (int i = c0 + lane; i < c1; i += WAVE) {
+    for (int i = c0 + lane; i < c1; i += NT) {
         int r = i / W, c = i - r * W;
         l.cls[i] = (unsigned char)((l.occ[r * WW + (c >> 6)] >> (c & 63)) & 1ull);
     }
-    __syncthreads();
-    for (int q = lane; q < l.hdr->npins; q += WAVE) {
+    lds_sync();
+    for (int q = lane; q < l.hdr->npins; q += NT) {
         const PinRec pr = l.pins[q];
         if (pr.abs_x >= r0 && pr.abs_x < r1 && pr.abs_y >= 0) l.cls[pr.abs_x * W + pr.abs_y] = (unsigned char)(pr.net + 2);
     }
-    __syncthreads();
+    lds_sync();
     unsigned char *dst = p.buf.pin_grid + (size_t)e * HW * K;
     const long long b0 = (long long)c0 * K, b1 = (long long)c1 * K;
     if ((b0 & 15) == 0 && (b1 & 15) == 0 && (((uintptr_t)dst) & 15) == 0) {
         uint4 *d4 = (uint4 *)dst;
-        for (int c = (int)(b0 / 16) + lane; c < (int)(b1 / 16); c += WAVE) {
-            int bb = c * 16, cell = bb / K, ch = bb - cell * K;
-            unsigned w[4] = {0, 0, 0, 0};
-            unsigned cl = l.cls[cell];
-            #pragma unroll
-            for (int k = 0; k < 16; k++) {
-                w[k >> 2] |= (unsigned)(cl == (unsigned)(ch + 1)) << (8 * (k & 3));
-                if (++ch == K) { ch = 0; cell++; cl = cell < c1 ? l.cls[cell] : 0; }
+        // every cell owns K consecutive bytes with at most one 1 (at class-1): visit the <= 16/K + 2 cells a
+        // 16-byte chunk overlaps and drop their 1-bytes into two 64-bit halves
+        const unsigned kinv = 0xFFFFFFFFu / (unsigned)K + 1u;  // floor(b / K) == umulhi(b, kinv) for b < 2^32 / K
+        for (int c = (int)(b0 / 16) + lane; c < (int)(b1 / 16); c += NT) {
+            const int bb = c * 16;
+            int cell = (int)__umulhi((unsigned)bb, kinv);
+            if (cell * K > bb) cell--;  // (never taken at these sizes; keeps the division exact regardless)
+            u64 lo = 0, hi = 0;
+            for (int base = cell * K; base < bb + 16 && cell < c1; base += K, cell++) {
+                const unsigned cl = l.cls[cell];
+                const int off = base + (int)cl - 1 - bb;  // byte of this cell's 1 inside the chunk
+                if (cl != 0 && off >= 0 && off < 16) {
+                    if (off < 8) lo |= 1ull << (8 * off); else hi |= 1ull << (8 * (off - 8));
+                }
             }
-            d4[c] = make_uint4(w[0], w[1], w[2], w[3]);
+            d4[c] = make_uint4((unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32));
         }
     } else {
-        for (long long i = b0 + lane; i < b1; i += WAVE) {
+        for (long long i = b0 + lane; i < b1; i += NT) {
             int cell = (int)(i / K), ch = (int)(i - (long long)cell * K);
             dst[i] = (unsigned char)(l.cls[cell] == ch + 1);
         }
@@ -647,21 +680,21 @@ __global__ __launch_bounds__(WAVE) void k_sample(DevParams p, int *__restrict__ 
 // ----------------------------------------------------------------------------------------------
 template <int KIND, int WW> __device__ inline void reset_env(const DevParams &p, Lds &l, int e, int lane) {
     const int H = p.H, W = p.W, HW = H * W;
-    __syncthreads();
-    for (int i = lane; i < H * WW; i += WAVE) l.occ[i] = 0ull;
+    lds_sync();
+    for (int i = lane; i < H * WW; i += NT) l.occ[i] = 0ull;
     if (KIND != PCBENV_SQUARE) {
         const unsigned slot = l.hdr->qcursor % (unsigned)p.Q;
         const unsigned char *rec = p.queue + ((size_t)slot * p.B + e) * p.instStride;
         const int *ih = (const int *)rec;
         const int nc = ih[0], nn = ih[1], np = ih[2];
         const unsigned char *crec = rec + 16, *prec = rec + 16 + 8 * (size_t)p.C;
-        for (int c = lane; c < p.C; c += WAVE) {
+        for (int c = lane; c < p.C; c += NT) {
             CompRec cr; cr.h = crec[8 * c]; cr.w = crec[8 * c + 1]; cr.px = -1; cr.py = -1;
             cr.pad[0] = cr.pad[1] = cr.pad[2] = cr.pad[3] = 0;
             if (c >= nc) { cr.h = 0; cr.w = 0; }
             l.comps[c] = cr;
         }
-        for (int q = lane; q < p.P; q += WAVE) {
+        for (int q = lane; q < p.P; q += NT) {
             PinRec pr; pr.rel_x = prec[8 * q]; pr.rel_y = prec[8 * q + 1]; pr.abs_x = -1; pr.abs_y = -1;
             pr.net = prec[8 * q + 2]; pr.comp = prec[8 * q + 3];
             pr.id = (unsigned short)(prec[8 * q + 4] | (prec[8 * q + 5] << 8));
@@ -672,9 +705,9 @@ template <int KIND, int WW> __device__ inline void reset_env(const DevParams &p,
             l.hdr->ncomp = (short)nc; l.hdr->nnets = (short)nn; l.hdr->npins = (short)np; l.hdr->cur = 0;
             l.hdr->qcursor += 1; l.hdr->episode += 1;
         }
-        __syncthreads();
+        lds_sync();
         if (KIND == PCBENV_PIN) {  // quirk Q1: rows [component, pin_id] collide; the last writer in self.pins order wins
-            for (int q = lane; q < np; q += WAVE) {
+            for (int q = lane; q < np; q += NT) {
                 bool loser = false;
                 for (int r = q + 1; r < np; r++)
                     loser |= (l.pins[r].comp == l.pins[q].comp && (l.pins[r].id & PIN_ID_MASK) == (l.pins[q].id & PIN_ID_MASK));
@@ -684,7 +717,7 @@ template <int KIND, int WW> __device__ inline void reset_env(const DevParams &p,
     } else if (lane == 0) {
         l.hdr->ncomp = 0; l.hdr->nnets = 0; l.hdr->npins = 0; l.hdr->cur = 0; l.hdr->episode += 1;
     }
-    __syncthreads();
+    lds_sync();
     current_mask<KIND, WW>(p, l, lane);
     emit_cells<KIND, WW>(p, l, e, lane, 0, H);
 
@@ -693,7 +726,7 @@ template <int KIND, int WW> __device__ inline void reset_env(const DevParams &p,
         // all_components_feature (R:60-79, S:203-239): [h, w, -1, -1, area/(H*W), (spatial: pin ids, -1 pad)]; absent rows 0
         if (p.buf.all_components_feature) {
             double *cf = p.buf.all_components_feature + (size_t)e * p.C * p.F;
-            for (int i = lane; i < p.C * p.F; i += WAVE) {
+            for (int i = lane; i < p.C * p.F; i += NT) {
                 const int c = i / p.F, k = i - c * p.F;
                 double v = 0.0;
                 if (c < nc) {
@@ -704,9 +737,9 @@ template <int KIND, int WW> __device__ inline void reset_env(const DevParams &p,
                 cf[i] = v;
             }
             if (KIND == PCBENV_SPATIAL) {  // pin ids of component.pins (self.pins order)
-                __syncthreads();
-                __threadfence_block();
-                for (int c = lane; c < nc; c += WAVE) {
+                __syncthreads();  // also orders this thread block's global stores (zero fill before the row writes)
+            __threadfence_block();
+                for (int c = lane; c < nc; c += NT) {
                     int k = 0;
                     for (int q = 0; q < np; q++) if (l.pins[q].comp == c) cf[c * p.F + 5 + k++] = (double)(l.pins[q].id & PIN_ID_MASK);
                 }
@@ -714,26 +747,26 @@ template <int KIND, int WW> __device__ inline void reset_env(const DevParams &p,
         }
         if (p.buf.placement_mask) {
             double *pm = p.buf.placement_mask + (size_t)e * p.C;
-            for (int c = lane; c < p.C; c += WAVE)
+            for (int c = lane; c < p.C; c += NT)
                 pm[c] = KIND == PCBENV_RECT ? 0.0 : (c == 0 ? 3.0 : (c < nc ? 1.0 : 0.0));
         }
         if (KIND == PCBENV_RECT && p.buf.component_mask) {
             double *cm = p.buf.component_mask + (size_t)e * p.C;
-            for (int c = lane; c < p.C; c += WAVE) cm[c] = c < nc ? 1.0 : 0.0;
+            for (int c = lane; c < p.C; c += NT) cm[c] = c < nc ? 1.0 : 0.0;
         }
         if (KIND == PCBENV_PIN || KIND == PCBENV_SPATIAL) {
             if (p.buf.all_pins_num_feature) {
                 double *f = p.buf.all_pins_num_feature + (size_t)e * p.pinRows * 4;
-                for (int i = lane; i < p.pinRows * 4; i += WAVE) f[i] = 0.0;
+                for (int i = lane; i < p.pinRows * 4; i += NT) f[i] = 0.0;
             }
             if (p.buf.all_pins_cat_feature) {
                 double *f = p.buf.all_pins_cat_feature + (size_t)e * p.pinRows * p.catW;
-                for (int i = lane; i < p.pinRows * p.catW; i += WAVE)
+                for (int i = lane; i < p.pinRows * p.catW; i += NT)
                     f[i] = (KIND == PCBENV_SPATIAL && i >= (p.pinRows - 1) * p.catW) ? -1.0 : 0.0;  // S:1520
             }
-            __syncthreads();
+            __syncthreads();  // also orders this thread block's global stores (zero fill before the row writes)
             __threadfence_block();
-            for (int q = lane; q < np; q += WAVE) {
+            for (int q = lane; q < np; q += NT) {
                 const PinRec pr = l.pins[q];
                 write_pin_num<KIND>(p, e, pr);
                 if (p.buf.all_pins_cat_feature) {
@@ -751,24 +784,24 @@ template <int KIND, int WW> __device__ inline void reset_env(const DevParams &p,
             if (p.buf.component_grid) {  // S:1677-1697 draw_components (unrotated rel coords; channel 0 == 1)
                 const int cgsz = p.mh * p.mw * p.K;
                 unsigned char *cg = p.buf.component_grid + (size_t)e * p.C * cgsz;
-                for (int i = lane; i < p.C * cgsz; i += WAVE) {
+                for (int i = lane; i < p.C * cgsz; i += NT) {
                     const int c = i / cgsz, k = i % p.K;
                     cg[i] = (unsigned char)(c < nc && k == 0);
                 }
-                __syncthreads();
-                __threadfence_block();
-                for (int q = lane; q < np; q += WAVE) {
+                __syncthreads();  // also orders this thread block's global stores (zero fill before the row writes)
+            __threadfence_block();
+                for (int q = lane; q < np; q += NT) {
                     const PinRec pr = l.pins[q];
                     cg[((size_t)pr.comp * p.mh * p.mw + pr.rel_x * p.mw + pr.rel_y) * p.K + pr.net + 1] = 1;
                 }
             }
         }
     }
-    __syncthreads();
+    lds_sync();
 }
 
-template <int KIND, int WW>
-__global__ __launch_bounds__(WAVE) void k_reset(DevParams p, const unsigned char *__restrict__ mask) {
+template <int KIND, int WW, int NW>
+__global__ __launch_bounds__(64 * NW) void k_reset(DevParams p, const unsigned char *__restrict__ mask) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int e = blockIdx.x, lane = threadIdx.x;
     if (mask && !mask[e]) return;
@@ -789,8 +822,8 @@ __global__ __launch_bounds__(WAVE) void k_reset(DevParams p, const unsigned char
 //   sampled != 0: the action is drawn here (same generator as k_sample) and written to `actions`
 //   PCBENV_FLAG_AUTO_RESET: a terminal transition is followed, in the same launch, by the reset
 // ----------------------------------------------------------------------------------------------
-template <int KIND, int WW>
-__global__ __launch_bounds__(WAVE) void k_step(DevParams p, int *__restrict__ actions, int fmt, int sampled,
+template <int KIND, int WW, int NW>
+__global__ __launch_bounds__(64 * NW) void k_step(DevParams p, int *__restrict__ actions, int fmt, int sampled,
                                                u64 seed, u64 first_env, u64 step_index) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int e = blockIdx.x, lane = threadIdx.x;
@@ -801,11 +834,16 @@ __global__ __launch_bounds__(WAVE) void k_step(DevParams p, int *__restrict__ ac
 
     int o, x, y;
     if (sampled) {
-        sample_action(l.vm, p, (int)first_env + e, lane, seed, step_index, &o, &x, &y);
-        if (lane == 0) {
-            if (fmt == PCBENV_ACTION_FLAT) actions[e] = o * HW + x * W + y;
-            else { actions[3 * e] = o; actions[3 * e + 1] = x; actions[3 * e + 2] = y; }
+        if (lane < WAVE) {  // wave 0 draws, the others take the result from LDS
+            sample_action(l.vm, p, (int)first_env + e, lane, seed, step_index, &o, &x, &y);
+            if (lane == 0) {
+                l.hdr->pad[0] = (unsigned)o; l.hdr->pad[1] = (unsigned)x; l.hdr->pad[2] = (unsigned)y;
+                if (fmt == PCBENV_ACTION_FLAT) actions[e] = o * HW + x * W + y;
+                else { actions[3 * e] = o; actions[3 * e + 1] = x; actions[3 * e + 2] = y; }
+            }
         }
+        lds_sync();
+        o = (int)l.hdr->pad[0]; x = (int)l.hdr->pad[1]; y = (int)l.hdr->pad[2];
     } else if (fmt == PCBENV_ACTION_FLAT) {  // utils/environment/env_wrappers.py:80-98, :184-199
         const int a = actions[e];
         if (a < 0 || a >= p.O * HW) { o = -1; x = y = 0; }
@@ -821,7 +859,7 @@ __global__ __launch_bounds__(WAVE) void k_step(DevParams p, int *__restrict__ ac
 
     if (lane == 0 && p.buf.info) { p.buf.info[2 * e] = nan(""); p.buf.info[2 * e + 1] = nan(""); }
     if (lane == 0 && p.pending) p.pending[e] = 0;
-    __syncthreads();
+    lds_sync();
 
     bool deferred = false;
     if (!valid) {  // terminal transition, state and observations unchanged (quirk Q8 iii)
@@ -840,7 +878,7 @@ __global__ __launch_bounds__(WAVE) void k_step(DevParams p, int *__restrict__ ac
         pw = (o & 1) ? cr.h : cr.w;
     }
     // update_grid: rows x..x+ph-1, columns y..y+pw-1
-    for (int r = x + lane; r < x + ph && r < H; r += WAVE) {
+    for (int r = x + lane; r < x + ph && r < H; r += NT) {
         for (int w = 0; w < WW; w++) {
             const int lo = max(y, 64 * w) - 64 * w, hi = min(y + pw, 64 * w + 64) - 64 * w;  // bit range in word w
             if (hi > lo) l.occ[r * WW + w] |= ((hi - lo) >= 64 ? ~0ull : ((1ull << (hi - lo)) - 1ull)) << lo;
@@ -850,7 +888,7 @@ __global__ __launch_bounds__(WAVE) void k_step(DevParams p, int *__restrict__ ac
         if (lane == 0) { l.comps[cur].px = (signed char)x; l.comps[cur].py = (signed char)y; }
         if (KIND == PCBENV_PIN || KIND == PCBENV_SPATIAL) {
             const int ch = l.comps[cur].h, cw = l.comps[cur].w;
-            for (int q = lane; q < l.hdr->npins; q += WAVE) {  // S:149-190 place_component
+            for (int q = lane; q < l.hdr->npins; q += NT) {  // S:149-190 place_component
                 PinRec pr = l.pins[q];
                 if (pr.comp != cur) continue;
                 const int rx = pr.rel_x, ry = pr.rel_y;
@@ -876,7 +914,7 @@ __global__ __launch_bounds__(WAVE) void k_step(DevParams p, int *__restrict__ ac
             l.hdr->cur = (short)next;
         }
     }
-    __syncthreads();
+    lds_sync();
     const bool any = current_mask<KIND, WW>(p, l, lane);
     const bool done = KIND == PCBENV_SQUARE ? !any : (l.hdr->cur < 0 || !any);  // S:1856-1869
     if (lane == 0) p.buf.done[e] = done ? 1 : 0;
@@ -899,8 +937,8 @@ __global__ __launch_bounds__(WAVE) void k_step(DevParams p, int *__restrict__ ac
 // routed terminal reward for reward_type beam / both (S:866-886, :905-928); runs after k_step, only for
 // environments whose step left `pending` set (all components placed).  One lane per net for the beam search.
 // ----------------------------------------------------------------------------------------------
-template <int KIND, int WW>
-__global__ __launch_bounds__(WAVE) void k_reward_routes(DevParams p) {
+template <int KIND, int WW, int NW>
+__global__ __launch_bounds__(64 * NW) void k_reward_routes(DevParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int e = blockIdx.x, lane = threadIdx.x;
     if (!p.pending[e]) return;
@@ -908,9 +946,9 @@ __global__ __launch_bounds__(WAVE) void k_reward_routes(DevParams p) {
     Lds l = carve(smem, p);
     const SegView v = seg_view(l.seg, p.P);
     net_offsets_and_centroids(v, l.hdr, l.pins, lane);
-    for (int n = lane; n < l.hdr->nnets; n += WAVE)
+    for (int n = lane; n < l.hdr->nnets; n += NT)
         beam_route_net(v, l.pins, v.nstart[n], v.nstart[n + 1] - v.nstart[n], p.beam_width);
-    __syncthreads();
+    lds_sync();
     double wsum; int cnt;
     count_and_length(v, l.hdr, l.pins, lane, &wsum, &cnt);
     if (p.reward_type == PCBENV_REWARD_BOTH) {  // S:609-627 lowest_num_intersections: ties keep the beam route
@@ -937,6 +975,7 @@ struct pcbenv {
     int device;
     DevParams dp;
     bool bound;
+    int threads;  // workgroup size (threads per environment)
     unsigned loaded_slots;  // bit s = slot s loaded for all environments at least once
     char err[256];
 };
@@ -1077,9 +1116,16 @@ extern "C" int pcbenv_create(const pcbenv_config *cfg, int device, pcbenv **out)
     d.instStride = align16(pcbenv_instance_stride(&c));
     // LDS scratch behind the state mirror
     d.ldsHf = (int)d.stateStride;
-    d.ldsCls = d.ldsHf + d.H * d.WW * 8;
-    d.ldsSeg = align16(d.ldsCls + (c.kind == PCBENV_SPATIAL ? d.H * d.W : 0));
-    d.ldsBytes = align16(d.ldsSeg + (is_pin_kind(c.kind) ? SEG_LDS_BYTES(d.P) : 0));
+    // the class map (pin_grid emission) and the route segments (terminal reward) are never live together
+    d.ldsCls = align16(d.ldsHf + d.H * d.WW * 8);
+    d.ldsSeg = d.ldsCls;
+    {
+        int cls = c.kind == PCBENV_SPATIAL ? d.H * d.W : 0, seg = is_pin_kind(c.kind) ? SEG_LDS_BYTES(d.P) : 0;
+        d.ldsBytes = align16(d.ldsCls + (cls > seg ? cls : seg));
+    }
+    // threads per environment: one wave up to 64x64 cells of output per plane, four waves above
+    env->threads = c.reserved == 64 || c.reserved == 256 ? c.reserved
+                   : ((long long)c.height * c.width * (c.kind == PCBENV_SPATIAL ? d.K + 5 : 5) > 64 * 1024 ? 256 : 64);
     if (hipSetDevice(device) != hipSuccess) { int r = fail(0, PCBENV_EHIP, "hipSetDevice failed (no such device?)"); delete env; return r; }
     size_t sbytes = (size_t)d.stateStride * d.B, qbytes = (size_t)d.instStride * d.B * d.Q;
     if (hipMalloc((void **)&d.state, sbytes) != hipSuccess || hipMalloc((void **)&d.queue, qbytes ? qbytes : 16) != hipSuccess ||
@@ -1162,18 +1208,21 @@ extern "C" int pcbenv_load_instances(pcbenv *env, const int32_t *env_ids, int32_
 
 template <int KIND> static int launch_reset(pcbenv *env, const uint8_t *mask, hipStream_t s) {
     const DevParams &d = env->dp;
-    if (d.WW == 1) hipLaunchKernelGGL((k_reset<KIND, 1>), dim3(d.B), dim3(WAVE), d.ldsBytes, s, d, mask);
-    else hipLaunchKernelGGL((k_reset<KIND, 2>), dim3(d.B), dim3(WAVE), d.ldsBytes, s, d, mask);
+#define LAUNCH_RESET(WW_, NW_) hipLaunchKernelGGL((k_reset<KIND, WW_, NW_>), dim3(d.B), dim3(64 * NW_), d.ldsBytes, s, d, mask)
+    if (d.WW == 1) { if (env->threads == 64) LAUNCH_RESET(1, 1); else LAUNCH_RESET(1, 4); }
+    else { if (env->threads == 64) LAUNCH_RESET(2, 1); else LAUNCH_RESET(2, 4); }
     return 0;
 }
 template <int KIND> static int launch_step(pcbenv *env, int *actions, int fmt, int sampled, u64 seed, u64 first_env,
                                            u64 step_index, hipStream_t s) {
     const DevParams &d = env->dp;
-    if (d.WW == 1) hipLaunchKernelGGL((k_step<KIND, 1>), dim3(d.B), dim3(WAVE), d.ldsBytes, s, d, actions, fmt, sampled, seed, first_env, step_index);
-    else hipLaunchKernelGGL((k_step<KIND, 2>), dim3(d.B), dim3(WAVE), d.ldsBytes, s, d, actions, fmt, sampled, seed, first_env, step_index);
+#define LAUNCH_STEP(WW_, NW_) hipLaunchKernelGGL((k_step<KIND, WW_, NW_>), dim3(d.B), dim3(64 * NW_), d.ldsBytes, s, d, actions, fmt, sampled, seed, first_env, step_index)
+    if (d.WW == 1) { if (env->threads == 64) LAUNCH_STEP(1, 1); else LAUNCH_STEP(1, 4); }
+    else { if (env->threads == 64) LAUNCH_STEP(2, 1); else LAUNCH_STEP(2, 4); }
     if ((KIND == PCBENV_PIN || KIND == PCBENV_SPATIAL) && env->cfg.reward_type != PCBENV_REWARD_CENTROID) {
-        if (d.WW == 1) hipLaunchKernelGGL((k_reward_routes<KIND, 1>), dim3(d.B), dim3(WAVE), d.ldsBytes, s, d);
-        else hipLaunchKernelGGL((k_reward_routes<KIND, 2>), dim3(d.B), dim3(WAVE), d.ldsBytes, s, d);
+#define LAUNCH_ROUTES(WW_, NW_) hipLaunchKernelGGL((k_reward_routes<KIND, WW_, NW_>), dim3(d.B), dim3(64 * NW_), d.ldsBytes, s, d)
+        if (d.WW == 1) { if (env->threads == 64) LAUNCH_ROUTES(1, 1); else LAUNCH_ROUTES(1, 4); }
+        else { if (env->threads == 64) LAUNCH_ROUTES(2, 1); else LAUNCH_ROUTES(2, 4); }
     }
     return 0;
 }

@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG, "libpcbenv.so")
+LIB_PATH = os.environ.get("PCBENV_LIB", os.path.join(_PKG, "libpcbenv.so"))  # override: A/B builds only
 
 PCBENV_OK, PCBENV_EINVAL, PCBENV_ELIMIT, PCBENV_EHIP, PCBENV_ESTATE = 0, -1, -2, -3, -4
 ACTION_TUPLE, ACTION_FLAT = 0, 1

@@ -46,7 +46,7 @@ def obs_spec(cfg: EnvConfig) -> Dict[str, tuple]:
 class BatchedPlacementEnv:
     def __init__(self, cfg: EnvConfig, num_envs: int, device="cuda:0", queue_depth: int = 1,
                  run_seed: int = 0, first_env_index: int = 0, incremental_obs: bool = False,
-                 auto_reset: bool = False):
+                 auto_reset: bool = False, threads_per_env: int = 0):
         cfg.validate()
         self.cfg, self.num_envs, self.queue_depth = cfg, int(num_envs), int(queue_depth)
         self.run_seed, self.first_env_index = int(run_seed), int(first_env_index)
@@ -58,6 +58,7 @@ class BatchedPlacementEnv:
         self._ccfg = _lib.make_config(cfg, num_envs, queue_depth,
                                       (_lib.FLAG_INCREMENTAL_OBS if incremental_obs else 0)
                                       | (_lib.FLAG_AUTO_RESET if auto_reset else 0))
+        self._ccfg.reserved = int(threads_per_env)  # 0 = auto; 64 / 128 / 256 threads (1 / 2 / 4 waves) per environment
         h = C.c_void_p()
         dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         _lib.check(self._L.pcbenv_create(C.byref(self._ccfg), dev_index, C.byref(h)))

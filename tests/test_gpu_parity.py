@@ -69,12 +69,13 @@ def test_golden_episodes_on_gpu(name):
     env.close()
 
 
-def _oracle_rollout(cfg, B, episodes, queue_depth=2, p_bad=0.02, incremental=False, auto_reset=False, fused=False):
+def _oracle_rollout(cfg, B, episodes, queue_depth=2, p_bad=0.02, incremental=False, auto_reset=False, fused=False,
+                    threads=0):
     """Device-sampled legal actions (plus a few corrupted ones); every observation, reward, done, info of every step
     must equal the CPU oracle's.  Covers reset_done() and the instance queue."""
     from oracle import oracle as orc
     env = BatchedPlacementEnv(cfg, B, queue_depth=queue_depth, run_seed=3, incremental_obs=incremental,
-                              auto_reset=auto_reset)
+                              auto_reset=auto_reset, threads_per_env=threads)
     inst = env.generate_instances()
     ob = orc.OracleBatch(cfg, B)
     packed = [pack_instances(cfg, s) for s in inst] if cfg.kind != KIND_SQUARE else None
@@ -180,3 +181,11 @@ def test_auto_reset_and_fused_sampling(name):
 def test_auto_reset_with_beam_routes():
     _oracle_rollout(named_config("c4", "both"), 16, episodes=3, auto_reset=True, fused=True)
     _oracle_rollout(EnvConfig.pin(12, 12, 5, 5, 2, 5, 2, 5, 8, 6, 3, 5, 7, 2, "beam", 2, 0.25), 24, episodes=3, p_bad=0.05, auto_reset=True)
+
+
+@pytest.mark.parametrize("threads", [64, 256])
+def test_threads_per_env_variants(threads):
+    _oracle_rollout(named_config("c3"), 16, episodes=2, threads=threads)
+    _oracle_rollout(named_config("c4", "both"), 16, episodes=2, threads=threads, auto_reset=True, fused=True)
+    _oracle_rollout(named_config("c5"), 4, episodes=1, queue_depth=1, p_bad=0.0, threads=threads, incremental=True)
+    _oracle_rollout(EnvConfig.spatial(10, 10, 3, 4, 2, 4, 2, 4, 6, 1, 2, 4, 5, 2, "beam", 2, 0.5), 16, episodes=2, threads=threads)

@@ -215,6 +215,7 @@ __device__ inline SegView seg_view(double *seg, int P) {
 // net_pins offsets (self.pins is net-major) and S:1229-1241 get_centroid per net (exact integer sums, one division)
 __device__ inline void net_offsets_and_centroids(const SegView &v, const EnvHdr *hdr, const PinRec *pins, int lane) {
     const int np = hdr->npins, nn = hdr->nnets;
+    lds_sync();  // the segment area aliases the class map of emit_pin_grid
     for (int q = lane; q < np; q += NT)
         if (q == 0 || pins[q].net != pins[q - 1].net) v.nstart[pins[q].net] = q;
     if (lane == 0) v.nstart[nn] = np;
@@ -495,16 +496,26 @@ __device__ inline void store_state(const unsigned char *smem, const DevParams &p
     for (int i = lane; i < (int)(p.stateStride / 16); i += NT) dst[i] = src[i];
 }
 
-// Mask of the current component (or zeros) into l.vm, both orientations.  Returns "some action is legal".
-template <int KIND, int WW> __device__ inline bool current_mask(const DevParams &p, Lds &l, int lane) {
-    const int H = p.H, W = p.W, plane = H * WW;
+// Mask of the current component (or zeros) into l.vm, both orientations, and -- when `emit` -- the grid rows
+// [gr0, gr1) and the action_mask planes, each written as soon as its bits exist so that the HBM write stream
+// starts before the second orientation is folded.  Returns "some action is legal".
+template <int KIND, int WW>
+__device__ inline bool mask_and_emit(const DevParams &p, Lds &l, int e, int lane, bool emit, int gr0, int gr1) {
+    const int H = p.H, W = p.W, HW = H * W, plane = H * WW;
     const int cur = l.hdr->cur;
+    unsigned char *m = (emit && p.buf.action_mask) ? p.buf.action_mask + (size_t)e * p.O * HW : 0;
+    if (emit && p.buf.grid) emit_plane<WW>(p.buf.grid + (size_t)e * HW, l.occ, gr0, gr1, W, lane);
     bool any = false;
     if (KIND == PCBENV_SQUARE) {
         any = window_mask<WW>(l.occ, l.hf, l.vm, H, W, p.component_n, p.component_n, lane, &l.hdr->flag);
-    } else if (cur >= 0) {
+        if (m) emit_plane<WW>(m, l.vm, 0, H, W, lane);
+        return any;
+    }
+    const bool four = (KIND == PCBENV_PIN || KIND == PCBENV_SPATIAL);  // S:1852-1853 mask[2] = mask[0], mask[3] = mask[1]
+    if (cur >= 0) {
         const int h = l.comps[cur].h, w = l.comps[cur].w;
         any = window_mask<WW>(l.occ, l.hf, l.vm, H, W, h, w, lane, &l.hdr->flag);
+        if (m) { emit_plane<WW>(m, l.vm, 0, H, W, lane); if (four) emit_plane<WW>(m + 2 * HW, l.vm, 0, H, W, lane); }
         if (h == w) {
             for (int i = lane; i < plane; i += NT) l.vm[plane + i] = l.vm[i];
             lds_sync();
@@ -514,24 +525,10 @@ template <int KIND, int WW> __device__ inline bool current_mask(const DevParams 
     } else {
         for (int i = lane; i < 2 * plane; i += NT) l.vm[i] = 0ull;
         lds_sync();
+        if (m) { emit_plane<WW>(m, l.vm, 0, H, W, lane); if (four) emit_plane<WW>(m + 2 * HW, l.vm, 0, H, W, lane); }
     }
+    if (m) { emit_plane<WW>(m + HW, l.vm + plane, 0, H, W, lane); if (four) emit_plane<WW>(m + 3 * HW, l.vm + plane, 0, H, W, lane); }
     return any;
-}
-
-// grid + action_mask planes (+ pin_grid for the spatial kind) of environment e from LDS state.
-// The grid is written for rows [gr0, gr1) only (the rows a step changed, or 0..H); the mask always in full.
-template <int KIND, int WW> __device__ inline void emit_cells(const DevParams &p, Lds &l, int e, int lane, int gr0, int gr1) {
-    const int H = p.H, W = p.W, HW = H * W, plane = H * WW;
-    if (p.buf.grid) emit_plane<WW>(p.buf.grid + (size_t)e * HW, l.occ, gr0, gr1, W, lane);
-    if (p.buf.action_mask) {
-        unsigned char *m = p.buf.action_mask + (size_t)e * p.O * HW;
-        emit_plane<WW>(m, l.vm, 0, H, W, lane);
-        if (KIND != PCBENV_SQUARE) emit_plane<WW>(m + HW, l.vm + plane, 0, H, W, lane);
-        if (KIND == PCBENV_PIN || KIND == PCBENV_SPATIAL) {  // S:1852-1853 mask[2] = mask[0], mask[3] = mask[1]
-            emit_plane<WW>(m + 2 * HW, l.vm, 0, H, W, lane);
-            emit_plane<WW>(m + 3 * HW, l.vm + plane, 0, H, W, lane);
-        }
-    }
 }
 
 // S:1663-1675 draw_pins: class map (0 empty, 1 occupied without pin, n+2 pin of net n) -> one-hot[:, :, 1:];
@@ -718,8 +715,7 @@ template <int KIND, int WW> __device__ inline void reset_env(const DevParams &p,
         l.hdr->ncomp = 0; l.hdr->nnets = 0; l.hdr->npins = 0; l.hdr->cur = 0; l.hdr->episode += 1;
     }
     lds_sync();
-    current_mask<KIND, WW>(p, l, lane);
-    emit_cells<KIND, WW>(p, l, e, lane, 0, H);
+    mask_and_emit<KIND, WW>(p, l, e, lane, true, 0, H);
 
     if (KIND != PCBENV_SQUARE) {
         const int nc = l.hdr->ncomp, np = l.hdr->npins;
@@ -915,21 +911,21 @@ __global__ __launch_bounds__(64 * NW) void k_step(DevParams p, int *__restrict__
         }
     }
     lds_sync();
-    const bool any = current_mask<KIND, WW>(p, l, lane);
+    // When the last component has just been placed and the reset follows in this launch, the terminal cell
+    // tensors would be overwritten at once: skip them (terminal by "no legal cell left" is rare and only
+    // costs a double write).
+    const bool inc = (p.flags & PCBENV_FLAG_INCREMENTAL_OBS) != 0;
+    const int r0 = inc ? x : 0, r1 = inc ? min(x + ph, H) : H;
+    const bool routed_later = (KIND == PCBENV_PIN || KIND == PCBENV_SPATIAL) && p.reward_type != PCBENV_REWARD_CENTROID;
+    const bool skip_emit = auto_reset && !routed_later && KIND != PCBENV_SQUARE && l.hdr->cur < 0;
+    const bool any = mask_and_emit<KIND, WW>(p, l, e, lane, !skip_emit, r0, r1);
+    if (KIND == PCBENV_SPATIAL && !skip_emit) emit_pin_grid<WW>(p, l, e, lane, r0, r1);
     const bool done = KIND == PCBENV_SQUARE ? !any : (l.hdr->cur < 0 || !any);  // S:1856-1869
     if (lane == 0) p.buf.done[e] = done ? 1 : 0;
     if (KIND == PCBENV_SQUARE || KIND == PCBENV_RECT) { if (lane == 0) p.buf.reward[e] = 1.0; }
     else if (!done) { if (lane == 0) p.buf.reward[e] = 0.0; }
     else deferred = terminal_reward<KIND>(p, l, e, lane);
-
-    if (done && auto_reset && !deferred) {
-        reset_env<KIND, WW>(p, l, e, lane);  // rewrites every observation: skip the terminal ones
-    } else {
-        const bool inc = (p.flags & PCBENV_FLAG_INCREMENTAL_OBS) != 0;
-        const int r0 = inc ? x : 0, r1 = inc ? min(x + ph, H) : H;
-        emit_cells<KIND, WW>(p, l, e, lane, r0, r1);
-        if (KIND == PCBENV_SPATIAL) emit_pin_grid<WW>(p, l, e, lane, r0, r1);
-    }
+    if (done && auto_reset && !deferred) reset_env<KIND, WW>(p, l, e, lane);  // rewrites every observation
     store_state(smem, p, e, lane);
 }
 

@@ -44,6 +44,8 @@ def obs_spec(cfg: EnvConfig) -> Dict[str, tuple]:
 
 
 class BatchedPlacementEnv:
+    is_batched = True
+
     def __init__(self, cfg: EnvConfig, num_envs: int, device="cuda:0", queue_depth: int = 1,
                  run_seed: int = 0, first_env_index: int = 0, incremental_obs: bool = False,
                  auto_reset: bool = False, threads_per_env: int = 0):

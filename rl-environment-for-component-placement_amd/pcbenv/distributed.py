@@ -1,0 +1,58 @@
+"""One process per GPU: environment sharding and the PPO-side advantage statistics.
+
+The environment path needs no communication: environments are independent, each
+rank owns a contiguous block of global environment indices and derives its
+instance streams from the *global* index, so results do not depend on the GPU
+count.  The only exchange in a PPO loop around this path is the advantage
+normalisation (RLlib standardises advantages over the whole train batch inside
+ray 2.2.0, which is not in the reference tree): every rank needs the global
+mean / std.  `torch.distributed` with backend "nccl" is RCCL over xGMI on ROCm;
+"gloo" runs the same code on CPU (tests).
+
+* `normalize_advantages(adv, mode="all_gather")`: the collective the north star
+  names -- all-gather of the per-rank advantages (c4: 16*4096*4 B = 256 KiB per
+  rank), then mean/std of the gathered vector on every rank.
+* `mode="all_reduce"`: the equivalent 3-scalar all-reduce (sum, sum of squares,
+  count) in float64 -- 24 bytes on the wire; latency-bound either way on
+  7 x 153 GB/s point-to-point links.
+"""
+from __future__ import annotations
+
+import os
+from typing import Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(num_envs_per_rank: int, rank: int = None) -> Tuple[int, int]:
+    """Global environment index range [first, last) owned by `rank`."""
+    if rank is None:
+        rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else int(os.environ.get("RANK", "0"))
+    return rank * num_envs_per_rank, (rank + 1) * num_envs_per_rank
+
+
+def global_mean_std(adv: torch.Tensor, mode: str = "all_gather", eps: float = 1e-8) -> Tuple[torch.Tensor, torch.Tensor]:
+    flat = adv.reshape(-1)
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    if world == 1:
+        return flat.mean(), flat.std(unbiased=False)
+    if mode == "all_gather":
+        out = torch.empty(world * flat.numel(), dtype=flat.dtype, device=flat.device)
+        dist.all_gather_into_tensor(out, flat.contiguous())
+        return out.mean(), out.std(unbiased=False)
+    if mode == "all_reduce":
+        f64 = flat.double()
+        s = torch.stack([f64.sum(), (f64 * f64).sum(), torch.tensor(float(flat.numel()), dtype=torch.float64, device=flat.device)])
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+        mean = s[0] / s[2]
+        var = torch.clamp(s[1] / s[2] - mean * mean, min=0.0)
+        return mean.to(flat.dtype), var.sqrt().to(flat.dtype)
+    raise ValueError(mode)
+
+
+def normalize_advantages(adv: torch.Tensor, mode: str = "all_gather", eps: float = 1e-8) -> torch.Tensor:
+    """(adv - global mean) / max(global std, eps): identical on every rank's shard to normalising the
+    concatenation of all shards."""
+    mean, std = global_mean_std(adv, mode, eps)
+    return (adv - mean) / torch.clamp(std, min=eps)

@@ -41,6 +41,33 @@ def algorithmic_bytes_per_env_step(cfg) -> int:
     return b
 
 
+def host_cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def measured_copy_ceiling_gbps(device):
+    """Device-to-device copy of 1 GiB (read + write), best of 5: the practical HBM ceiling next to the 8 TB/s spec."""
+    n = 1 << 30
+    a = torch.empty(n, dtype=torch.uint8, device=device)
+    b = torch.empty(n, dtype=torch.uint8, device=device)
+    best = 0.0
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        best = max(best, 2 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    del a, b
+    return best
+
+
 def cpu_baseline(cfg, run_seed, sample_envs, sample_steps, queue_depth):
     """Time the CPU oracle (port of the reference) on a bounded sample; parity-check it against the GPU."""
     from oracle import oracle as orc
@@ -180,6 +207,13 @@ def main():
 
     if rank == 0:
         b_alg = algorithmic_bytes_per_env_step(cfg)
+        if args.incremental:
+            # only the rows of the placed rectangle are rewritten in grid / pin_grid: count what is moved
+            from pcbenv.config import KIND_SPATIAL
+            rows = (cfg.min_component_h + cfg.max_component_h + cfg.min_component_w + cfg.max_component_w) / 4.0
+            per_row = cfg.width * (1 + (cfg.max_num_nets + 1 if cfg.kind == KIND_SPATIAL else 0))
+            b_alg = int(cfg.num_orientations * cfg.height * cfg.width + rows * per_row
+                        + 2 * 8 * (cfg.max_num_components + cfg.max_total_pins) + 2 * 3 * cfg.height * ((cfg.width + 63) // 64) * 8)
         value = world * B * args.steps / elapsed
         roof = None
         if step_kernel_ms:
@@ -193,6 +227,7 @@ def main():
                     traffic = None
             roof = {"bound": "hbm", "kernel": "k_step", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                     "frac": round(achieved / 8000.0, 4), "traffic": traffic,
+                    "measured_copy_ceiling": round(measured_copy_ceiling_gbps(env.device), 1),
                     "algorithmic_bytes_per_env_step": b_alg, "units_per_launch": B,
                     "kernel_ms": round(step_kernel_ms, 5)}
         cpu = None
@@ -202,7 +237,8 @@ def main():
             nthr = max(res)
             cpu = {"value": round(res[nthr][0], 1), "unit": "env-steps/s", "cores": nthr, "kind": "port",
                    "sample": f"{sample_envs} envs x {sample_steps} steps of the same instances and action stream (oracle/pcbenv_oracle.c, OpenMP)",
-                   "single_thread_value": round(res[1][0], 1), "parity_with_gpu": bool(all(v[1] for v in res.values()))}
+                   "single_thread_value": round(res[1][0], 1), "parity_with_gpu": bool(all(v[1] for v in res.values())),
+                   "cpu_model": host_cpu_model(), "host_logical_cpus": os.cpu_count()}
         line = {"metric": "env_steps_per_sec", "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u64 bit-rows + f64 reward",

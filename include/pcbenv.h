@@ -172,6 +172,12 @@ int pcbenv_sample_actions(pcbenv *env, int32_t *actions_dev, int32_t action_form
 int pcbenv_step_sampled(pcbenv *env, int32_t *actions_out_dev, int32_t action_format, uint64_t seed,
                         uint64_t first_env_index, uint64_t step_index, void *stream);
 
+/* Checkpoint / resume of the library-owned environment state (all state blocks, pcbenv_state_bytes() bytes of
+ * host memory; the instance queue is an input and is reloaded by the caller).  Synchronous w.r.t. `stream`. */
+int64_t pcbenv_state_bytes(const pcbenv *env);
+int pcbenv_get_state(pcbenv *env, void *host_dst, void *stream);
+int pcbenv_set_state(pcbenv *env, const void *host_src, void *stream);
+
 /* Bit-packed legal-action mask of the current component, library-owned device
  * memory: uint64 [B, 2, H, ceil(W/64)] (orientation 0/1; pin kinds: 2 = 0, 3 = 1;
  * square: plane 0 only), bit y of word [b, o, x, y/64] = action_mask[b, o, x, y].

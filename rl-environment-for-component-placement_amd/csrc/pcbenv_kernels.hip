@@ -1298,3 +1298,25 @@ extern "C" const uint64_t *pcbenv_mask_bits(const pcbenv *env, int64_t *env_stri
     if (env_stride_bytes) *env_stride_bytes = env->dp.stateStride;
     return (const uint64_t *)(env->dp.state + env->dp.offVm);
 }
+
+extern "C" int64_t pcbenv_state_bytes(const pcbenv *env) {
+    return env ? (int64_t)env->dp.stateStride * env->dp.B + env->dp.B : 0;
+}
+extern "C" int pcbenv_get_state(pcbenv *env, void *host_dst, void *stream) {
+    if (!env || !host_dst) return fail(env, PCBENV_EINVAL, "null argument");
+    HIP_TRY(env, hipSetDevice(env->device));
+    const size_t sb = (size_t)env->dp.stateStride * env->dp.B;
+    HIP_TRY(env, hipMemcpyAsync(host_dst, env->dp.state, sb, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(env, hipMemcpyAsync((char *)host_dst + sb, env->dp.pending, (size_t)env->dp.B, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(env, hipStreamSynchronize((hipStream_t)stream));
+    return PCBENV_OK;
+}
+extern "C" int pcbenv_set_state(pcbenv *env, const void *host_src, void *stream) {
+    if (!env || !host_src) return fail(env, PCBENV_EINVAL, "null argument");
+    HIP_TRY(env, hipSetDevice(env->device));
+    const size_t sb = (size_t)env->dp.stateStride * env->dp.B;
+    HIP_TRY(env, hipMemcpyAsync(env->dp.state, host_src, sb, hipMemcpyHostToDevice, (hipStream_t)stream));
+    HIP_TRY(env, hipMemcpyAsync(env->dp.pending, (const char *)host_src + sb, (size_t)env->dp.B, hipMemcpyHostToDevice, (hipStream_t)stream));
+    HIP_TRY(env, hipStreamSynchronize((hipStream_t)stream));
+    return PCBENV_OK;
+}

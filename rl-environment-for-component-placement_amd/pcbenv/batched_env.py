@@ -43,6 +43,17 @@ def obs_spec(cfg: EnvConfig) -> Dict[str, tuple]:
             "all_pins_cat_feature": ((Cc * mp + 1, 2), f64)}
 
 
+class _ExternalBlock:
+    """__cuda_array_interface__ view over library-owned device memory (no ownership)."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def _as_tensor(ptr: int, nbytes: int, device) -> torch.Tensor:
+    return torch.as_tensor(_ExternalBlock(ptr, nbytes), device=device)
+
+
 class BatchedPlacementEnv:
     is_batched = True
 
@@ -188,6 +199,35 @@ class BatchedPlacementEnv:
             self._h, out.data_ptr(), _lib.ACTION_FLAT if flat else _lib.ACTION_TUPLE, self.run_seed,
             self.first_env_index, int(step_index), self._stream()), self._h)
         return self.obs, self.reward, self.done, self.info, out
+
+    # -- checkpoint / resume ------------------------------------------------------------------
+    def state_dict(self) -> dict:
+        """Library state + observation tensors (host copies).  The reference never serialises env state
+        (SURVEY.md §5); this is what a resumable rollout needs.  The instance queue is reloaded separately."""
+        n = self._L.pcbenv_state_bytes(self._h)
+        buf = np.empty(n, np.uint8)
+        _lib.check(self._L.pcbenv_get_state(self._h, buf.ctypes.data, self._stream()), self._h)
+        d = {"state": buf, "reward": self.reward.cpu(), "done": self.done.cpu(), "info": self.info_raw.cpu()}
+        d.update({"obs/" + k: v.cpu() for k, v in self.obs.items()})
+        return d
+
+    def load_state_dict(self, d: dict):
+        buf = np.ascontiguousarray(d["state"], np.uint8)
+        if buf.size != self._L.pcbenv_state_bytes(self._h):
+            raise ValueError("state size does not match this environment")
+        _lib.check(self._L.pcbenv_set_state(self._h, buf.ctypes.data, self._stream()), self._h)
+        self.reward.copy_(d["reward"]); self.done.copy_(d["done"]); self.info_raw.copy_(d["info"])
+        for k, v in self.obs.items():
+            v.copy_(d["obs/" + k])
+
+    def mask_bits(self) -> torch.Tensor:
+        """Bit-packed legal-action mask, int64 [B, 2, H, ceil(W/64)] (a copy; bit y of word [b, o, x, y // 64])."""
+        stride = C.c_int64()
+        ptr = self._L.pcbenv_mask_bits(self._h, C.byref(stride))
+        H, WW = self.cfg.height, (self.cfg.width + 63) // 64
+        nbytes = stride.value * self.num_envs
+        raw = _as_tensor(ptr, nbytes, self.device)  # library-owned block, wrapped without taking ownership
+        return raw.view(self.num_envs, stride.value)[:, :2 * H * WW * 8].contiguous().view(torch.int64).view(self.num_envs, 2, H, WW)
 
     # reference-style attribute access
     @property

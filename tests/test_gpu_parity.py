@@ -189,3 +189,67 @@ def test_threads_per_env_variants(threads):
     _oracle_rollout(named_config("c4", "both"), 16, episodes=2, threads=threads, auto_reset=True, fused=True)
     _oracle_rollout(named_config("c5"), 4, episodes=1, queue_depth=1, p_bad=0.0, threads=threads, incremental=True)
     _oracle_rollout(EnvConfig.spatial(10, 10, 3, 4, 2, 4, 2, 4, 6, 1, 2, 4, 5, 2, "beam", 2, 0.5), 16, episodes=2, threads=threads)
+
+
+def test_state_dict_roundtrip_and_mask_bits():
+    cfg = named_config("c4")
+    env = BatchedPlacementEnv(cfg, 12, queue_depth=2, run_seed=9)
+    env.generate_instances()
+    env.reset()
+    for t in range(5):
+        env.step(env.sample_actions(t))
+    snap = env.state_dict()
+    bits = env.mask_bits().cpu().numpy().view(np.uint64)
+    m = env.obs["action_mask"].cpu().numpy()
+    for b in range(12):  # bit y of word [b, o, x, 0] == action_mask[b, o, x, y]
+        for o in (0, 1):
+            unpacked = ((bits[b, o, :, 0][:, None] >> np.arange(64, dtype=np.uint64)[None, :]) & np.uint64(1)).astype(np.uint8)
+            assert np.array_equal(unpacked, m[b, o])
+    trace = []
+    for t in range(5, 12):
+        o, r, d, _ = env.step(env.sample_actions(t))
+        trace.append((r.cpu().numpy().copy(), d.cpu().numpy().copy(), o["pin_grid"].cpu().numpy().copy()))
+    env.load_state_dict(snap)
+    for t in range(5, 12):
+        o, r, d, _ = env.step(env.sample_actions(t))
+        r0, d0, g0 = trace[t - 5]
+        assert np.array_equal(r.cpu().numpy().view(np.uint64), r0.view(np.uint64)) and np.array_equal(d.cpu().numpy(), d0)
+        assert np.array_equal(o["pin_grid"].cpu().numpy(), g0)
+    env.close()
+
+
+def test_rollout_driver_matches_oracle_returns():
+    """Trajectory buffers on device; per-episode returns of the uniform random policy == the oracle's on the
+    recorded action stream (counterpart of the reference's simulate() loop)."""
+    from oracle import oracle as orc
+    from pcbenv import rollout
+    cfg = named_config("c3")
+    B, T, Q = 16, 40, 3
+    env = BatchedPlacementEnv(cfg, B, queue_depth=Q, run_seed=4, auto_reset=True)
+    inst = env.generate_instances()
+    env.reset()
+    traj = rollout.collect(env, T, store_obs=("placement_mask",))
+    ob = orc.OracleBatch(cfg, B)
+    packed = [pack_instances(cfg, s) for s in inst]
+    cursor = np.zeros(B, np.int64)
+
+    def oreset(mask):
+        ob.reset_packed(np.stack([packed[cursor[i] % Q][i] for i in range(B)]), mask.astype(np.uint8))
+        cursor[mask.astype(bool)] += 1
+    oreset(np.ones(B, np.uint8))
+    acts = traj.actions.cpu().numpy()
+    for t in range(T):
+        r, d, _ = ob.step(acts[t])
+        assert np.array_equal(r.view(np.uint64), traj.rewards[t].cpu().numpy().view(np.uint64))
+        assert np.array_equal(d, traj.dones[t].cpu().numpy())
+        oreset(d)
+    rets = traj.episode_returns()
+    assert all(len(e) == 2 for e in rets) and all(x < 0 for e in rets for x in e)  # 40 steps = 2 full episodes of 16
+    # a policy callable: masked categorical over flat logits never picks an illegal action
+    env2 = BatchedPlacementEnv(cfg, B, queue_depth=1, run_seed=4)
+    env2.generate_instances(); env2.reset()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    pol = lambda obs: rollout.sample_masked_categorical(torch.zeros((B, 4 * 64 * 64), device="cuda"), obs["action_mask"].reshape(B, -1), g)
+    tr2 = rollout.collect(env2, 16, policy=pol)
+    assert int(tr2.dones[:15].sum()) == 0 and int(tr2.dones[15].sum()) == B
+    env.close(); env2.close()

@@ -75,8 +75,7 @@ def cpu_baseline(cfg, run_seed, sample_envs, sample_steps, queue_depth):
     from pcbenv.batched_env import BatchedPlacementEnv
     from pcbenv.config import KIND_SQUARE
     env = BatchedPlacementEnv(cfg, sample_envs, queue_depth=queue_depth, run_seed=run_seed)
-    inst = env.generate_instances()
-    packed = [pack_instances(cfg, s) for s in inst] if cfg.kind != KIND_SQUARE else None
+    packed = env.generate_instances(verify=16) if cfg.kind != KIND_SQUARE else None
     env.reset()
     acts, dones, rewards = [], [], []
     for t in range(sample_steps):  # record the action stream on the GPU

@@ -12,6 +12,7 @@
  *                            environment/dummy_env_rectangular_pin.py:396-641
  *                            environment/dummy_env_rectangular_pin_spatial.py:396-607
  *                          and the factory utils/agent/utils.py:317-418 (init_env/create_env)
+ *   pcbenv_instgen_*       generate_instances() itself (NumPy legacy RandomState + CPython random restated)
  *   pcbenv_load_instances  the tables generate_instances() draws at reset
  *                            ..._spatial.py:960-989 (and :931-1212, :1408-1443)
  *   pcbenv_reset           DummyPlacementEnv.reset   ..._spatial.py:1487-1549,
@@ -171,6 +172,16 @@ int pcbenv_sample_actions(pcbenv *env, int32_t *actions_dev, int32_t action_form
  * stores it in actions_out_dev (the trajectory record) and applies it. */
 int pcbenv_step_sampled(pcbenv *env, int32_t *actions_out_dev, int32_t action_format, uint64_t seed,
                         uint64_t first_env_index, uint64_t step_index, void *stream);
+
+/* Native host-side instance generator: stream `seed` (< 2^32) yields, record by record (wire format above), the
+ * instances the reference's generate_instances() draws after `np.random.seed(seed); random.seed(seed)`
+ * (dummy_env_rectangular_pin_spatial.py:931-1212, :1408-1443; rect/pin siblings).  Not for PCBENV_SQUARE.
+ * pcbenv_instgen_next_batch advances n independent streams with `threads` host threads. */
+typedef struct pcbenv_instgen pcbenv_instgen;
+int pcbenv_instgen_create(const pcbenv_config *cfg, uint64_t seed, pcbenv_instgen **out);
+void pcbenv_instgen_destroy(pcbenv_instgen *gen);
+int pcbenv_instgen_next(pcbenv_instgen *gen, void *record_out);
+int pcbenv_instgen_next_batch(pcbenv_instgen *const *streams, int32_t n, void *records_out, int32_t threads);
 
 /* Checkpoint / resume of the library-owned environment state (all state blocks, pcbenv_state_bytes() bytes of
  * host memory; the instance queue is an input and is reloaded by the caller).  Synchronous w.r.t. `stream`. */

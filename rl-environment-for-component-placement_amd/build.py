@@ -10,7 +10,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
-SRC = [os.path.join(HERE, "csrc", "pcbenv_kernels.hip")]
+SRC = [os.path.join(HERE, "csrc", "pcbenv_kernels.hip"), os.path.join(HERE, "csrc", "instance_gen.cpp")]
 DEPS = SRC + [os.path.join(REPO, "include", "pcbenv.h")]
 OUT = os.path.join(HERE, "libpcbenv.so")
 
@@ -26,7 +26,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(s) for s in DEPS):
         return OUT
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
-           "-Wno-unused-value", "-I", os.path.join(REPO, "include"), "-o", OUT] + SRC
+           "-Wno-unused-value", "-pthread", "-I", os.path.join(REPO, "include"), "-o", OUT] + SRC
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -96,6 +96,7 @@ class BatchedPlacementEnv:
             setattr(bufs, name, t.data_ptr() if t is not None else None)
         _lib.check(self._L.pcbenv_bind_buffers(self._h, C.byref(bufs)), self._h)
         self._streams: Optional[List[InstanceStream]] = None
+        self._native = None
         torch.cuda.synchronize(self.device)
 
     # -- lifetime ---------------------------------------------------------------------------
@@ -128,21 +129,49 @@ class BatchedPlacementEnv:
             self._h, None if ids is None else ids.ctypes.data, packed.shape[0], slot, packed.ctypes.data,
             self._stream()), self._h)
 
-    def generate_instances(self) -> List[List[Instance]]:
+    def generate_instances(self, native: bool = True, verify: int = 0, threads: int = 8):
         """Fill every queue slot from per-environment reference RNG streams (seed = f(run_seed, global env index)):
-        slot s holds each environment's s-th reset instance, exactly what the reference env seeded with that
-        stream seed would draw at its s-th `reset()`."""
+        slot s holds each environment's next reset instance, exactly what the reference env seeded with that
+        stream seed would draw at that `reset()`.  `native=True` uses libpcbenv.so's generator
+        (csrc/instance_gen.cpp, ~100x faster); `native=False` the NumPy/`random`-calling `InstanceStream`;
+        `verify=n` cross-checks the first n environments of every slot between the two.
+        Returns the packed records per slot (uint8 [B, instance_stride])."""
         if self.cfg.kind == KIND_SQUARE:
             return []
-        if self._streams is None:
-            self._streams = [InstanceStream(self.cfg, env_seed(self.run_seed, self.first_env_index + i))
-                             for i in range(self.num_envs)]
+        seeds = [env_seed(self.run_seed, self.first_env_index + i) for i in range(self.num_envs)]
+        if native and self._native is None:
+            from .instances import NativeInstanceStreams
+            self._native = NativeInstanceStreams(self.cfg, seeds, threads)
+        if (not native or verify) and self._streams is None:
+            n = self.num_envs if not native else min(verify, self.num_envs)
+            self._streams = [InstanceStream(self.cfg, seeds[i]) for i in range(n)]
         out = []
         for s in range(self.queue_depth):
-            inst = [st.next() for st in self._streams]
-            self.load_instances(inst, slot=s)
-            out.append(inst)
+            if native:
+                packed = self._native.next_packed()
+                if verify:
+                    ref = pack_instances(self.cfg, [st.next() for st in self._streams])
+                    if not np.array_equal(packed[:len(ref)], ref):
+                        raise RuntimeError("native instance generator disagrees with InstanceStream")
+            else:
+                packed = np.ascontiguousarray(pack_instances(self.cfg, [st.next() for st in self._streams]))
+            self.load_packed(packed, slot=s)
+            out.append(packed)
         return out
+
+    def refill_slot(self, slot: int, native: bool = True):
+        """Overwrite one queue slot with every environment's next instance (call when no environment can be
+        about to read that slot, e.g. between rollouts; copies are ordered on the current stream)."""
+        if self.cfg.kind == KIND_SQUARE:
+            return None
+        if native:
+            if self._native is None:
+                raise RuntimeError("call generate_instances(native=True) first")
+            packed = self._native.next_packed()
+        else:
+            packed = np.ascontiguousarray(pack_instances(self.cfg, [st.next() for st in self._streams]))
+        self.load_packed(packed, slot=slot)
+        return packed
 
     # -- gym-style API ----------------------------------------------------------------------
     def reset(self, mask: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:

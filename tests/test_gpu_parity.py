@@ -76,9 +76,8 @@ def _oracle_rollout(cfg, B, episodes, queue_depth=2, p_bad=0.02, incremental=Fal
     from oracle import oracle as orc
     env = BatchedPlacementEnv(cfg, B, queue_depth=queue_depth, run_seed=3, incremental_obs=incremental,
                               auto_reset=auto_reset, threads_per_env=threads)
-    inst = env.generate_instances()
+    packed = env.generate_instances(verify=4) if cfg.kind != KIND_SQUARE else None
     ob = orc.OracleBatch(cfg, B)
-    packed = [pack_instances(cfg, s) for s in inst] if cfg.kind != KIND_SQUARE else None
     cursor = np.zeros(B, np.int64)
 
     def oracle_reset(mask):
@@ -226,11 +225,10 @@ def test_rollout_driver_matches_oracle_returns():
     cfg = named_config("c3")
     B, T, Q = 16, 40, 3
     env = BatchedPlacementEnv(cfg, B, queue_depth=Q, run_seed=4, auto_reset=True)
-    inst = env.generate_instances()
+    packed = env.generate_instances(native=False)
     env.reset()
     traj = rollout.collect(env, T, store_obs=("placement_mask",))
     ob = orc.OracleBatch(cfg, B)
-    packed = [pack_instances(cfg, s) for s in inst]
     cursor = np.zeros(B, np.int64)
 
     def oreset(mask):

@@ -122,6 +122,10 @@ typedef struct pcbenv_buffers {
     uint8_t *done;                  /* [B]   required                                       */
     double *info;                   /* [B, 2] = (wirelength, num_intersections); NaN where the reference's
                                        info dict is empty                       pin/spatial */
+    /* marginals of action_mask for the factorised policies p(o) p(x|o) p(y|o,x), straight from the bit rows
+     * (utils/agent/factorized_action_distributions.py:358 reduce_max over (H, W); :401 reduce_max over W) */
+    uint8_t *mask_orientation;      /* [B, O]    = max over (x, y) of action_mask     optional, all kinds */
+    uint8_t *mask_rows;             /* [B, O, H] = max over y of action_mask          optional, all kinds */
 } pcbenv_buffers;
 
 /* Instance wire format (host memory), one record of pcbenv_instance_stride() bytes:

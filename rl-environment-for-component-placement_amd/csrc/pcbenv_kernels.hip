@@ -496,6 +496,28 @@ __device__ inline void store_state(const unsigned char *smem, const DevParams &p
     for (int i = lane; i < (int)(p.stateStride / 16); i += NT) dst[i] = src[i];
 }
 
+// Marginals of the legal mask for factorised policies (factorized_action_distributions.py:358, :401): per
+// orientation "any legal cell" and per (orientation, row) "any legal column", read off the bit rows in LDS.
+template <int KIND, int WW> __device__ inline void emit_marginals(const DevParams &p, Lds &l, int e, int lane) {
+    if (!p.buf.mask_rows && !p.buf.mask_orientation) return;
+    const int H = p.H, plane = H * WW, O = p.O;
+    for (int i = lane; i < O * H; i += NT) {
+        const int o = i / H, r = i - o * H;
+        const u64 *row = l.vm + (o & 1) * plane + r * WW;
+        bool a = false;
+        for (int w = 0; w < WW; w++) a |= row[w] != 0;
+        if (p.buf.mask_rows) p.buf.mask_rows[(size_t)e * O * H + i] = a ? 1 : 0;
+    }
+    if (p.buf.mask_orientation) {
+        for (int o = (int)(lane / WAVE); o < O; o += NT / WAVE) {  // one wavefront per orientation
+            bool a = false;
+            for (int i = (lane & 63); i < plane; i += WAVE) a |= l.vm[(o & 1) * plane + i] != 0;
+            a = __any(a);
+            if ((lane & 63) == 0) p.buf.mask_orientation[(size_t)e * O + o] = a ? 1 : 0;
+        }
+    }
+}
+
 // Mask of the current component (or zeros) into l.vm, both orientations, and -- when `emit` -- the grid rows
 // [gr0, gr1) and the action_mask planes, each written as soon as its bits exist so that the HBM write stream
 // starts before the second orientation is folded.  Returns "some action is legal".
@@ -509,6 +531,7 @@ __device__ inline bool mask_and_emit(const DevParams &p, Lds &l, int e, int lane
     if (KIND == PCBENV_SQUARE) {
         any = window_mask<WW>(l.occ, l.hf, l.vm, H, W, p.component_n, p.component_n, lane, &l.hdr->flag);
         if (m) emit_plane<WW>(m, l.vm, 0, H, W, lane);
+        if (emit) emit_marginals<KIND, WW>(p, l, e, lane);
         return any;
     }
     const bool four = (KIND == PCBENV_PIN || KIND == PCBENV_SPATIAL);  // S:1852-1853 mask[2] = mask[0], mask[3] = mask[1]
@@ -528,6 +551,7 @@ __device__ inline bool mask_and_emit(const DevParams &p, Lds &l, int e, int lane
         if (m) { emit_plane<WW>(m, l.vm, 0, H, W, lane); if (four) emit_plane<WW>(m + 2 * HW, l.vm, 0, H, W, lane); }
     }
     if (m) { emit_plane<WW>(m + HW, l.vm + plane, 0, H, W, lane); if (four) emit_plane<WW>(m + 3 * HW, l.vm + plane, 0, H, W, lane); }
+    if (emit) emit_marginals<KIND, WW>(p, l, e, lane);
     return any;
 }
 

@@ -33,7 +33,7 @@ class PcbenvConfig(C.Structure):
 
 BUFFER_FIELDS = ("grid", "action_mask", "pin_grid", "component_grid", "all_components_feature",
                  "placement_mask", "component_mask", "all_pins_num_feature", "all_pins_cat_feature",
-                 "reward", "done", "info")
+                 "reward", "done", "info", "mask_orientation", "mask_rows")
 
 
 class PcbenvBuffers(C.Structure):

@@ -59,7 +59,8 @@ class BatchedPlacementEnv:
 
     def __init__(self, cfg: EnvConfig, num_envs: int, device="cuda:0", queue_depth: int = 1,
                  run_seed: int = 0, first_env_index: int = 0, incremental_obs: bool = False,
-                 auto_reset: bool = False, threads_per_env: int = 0):
+                 auto_reset: bool = False, threads_per_env: int = 0,
+                 mask_marginals: bool = False):
         cfg.validate()
         self.cfg, self.num_envs, self.queue_depth = cfg, int(num_envs), int(queue_depth)
         self.run_seed, self.first_env_index = int(run_seed), int(first_env_index)
@@ -84,6 +85,10 @@ class BatchedPlacementEnv:
             self.done = torch.zeros(B, dtype=torch.uint8, device=self.device)
             self.info_raw = torch.full((B, 2), float("nan"), dtype=torch.float64, device=self.device)
             self._actions = torch.zeros((B, 3), dtype=torch.int32, device=self.device)
+            O = cfg.num_orientations
+            # marginals of action_mask for factorised policies (not reference observation keys)
+            self.mask_marginals = {"orientation": torch.zeros((B, O), dtype=torch.uint8, device=self.device),
+                                   "rows": torch.zeros((B, O, cfg.height), dtype=torch.uint8, device=self.device)} if mask_marginals else {}
         bufs = _lib.PcbenvBuffers()
         for name in _lib.BUFFER_FIELDS:
             t = self.obs.get(name)
@@ -93,6 +98,10 @@ class BatchedPlacementEnv:
                 t = self.done
             elif name == "info":
                 t = self.info_raw if cfg.kind in (KIND_PIN, KIND_SPATIAL) else None
+            elif name == "mask_orientation":
+                t = self.mask_marginals.get("orientation")
+            elif name == "mask_rows":
+                t = self.mask_marginals.get("rows")
             setattr(bufs, name, t.data_ptr() if t is not None else None)
         _lib.check(self._L.pcbenv_bind_buffers(self._h, C.byref(bufs)), self._h)
         self._streams: Optional[List[InstanceStream]] = None

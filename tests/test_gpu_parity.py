@@ -251,3 +251,19 @@ def test_rollout_driver_matches_oracle_returns():
     tr2 = rollout.collect(env2, 16, policy=pol)
     assert int(tr2.dones[:15].sum()) == 0 and int(tr2.dones[15].sum()) == B
     env.close(); env2.close()
+
+
+def test_mask_marginals_for_factorised_policies():
+    """reduce_max over (H, W) and over W of action_mask (factorized_action_distributions.py:358, :401)."""
+    for name, threads in (("c2", 0), ("c4", 0), ("c5", 256), ("c1", 0)):
+        cfg = named_config(name)
+        B = 6
+        env = BatchedPlacementEnv(cfg, B, queue_depth=1, run_seed=2, mask_marginals=True, threads_per_env=threads)
+        env.generate_instances()
+        env.reset()
+        for t in range(10):
+            m = env.obs["action_mask"].reshape(B, cfg.num_orientations, cfg.height, cfg.width)
+            assert torch.equal(env.mask_marginals["orientation"], m.amax(dim=(2, 3)))
+            assert torch.equal(env.mask_marginals["rows"], m.amax(dim=3))
+            env.step(env.sample_actions(t))
+        env.close()

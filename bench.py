@@ -121,11 +121,16 @@ def main():
     ap.add_argument("--queue-depth", type=int, default=2)
     ap.add_argument("--run-seed", type=int, default=0)
     ap.add_argument("--incremental", action="store_true", help="PCBENV_FLAG_INCREMENTAL_OBS")
+    ap.add_argument("--chunk", type=int, default=1,
+                    help="fused loop only: issue this many steps per host call (pcbenv_rollout_sampled)")
     ap.add_argument("--loop", default="fused", choices=["fused", "explicit"],
                     help="fused: one launch per step (pcbenv_step_sampled + PCBENV_FLAG_AUTO_RESET); "
                          "explicit: sample_actions, step, reset_done as three launches (reference-style loop)")
     ap.add_argument("--threads-per-env", type=int, default=0)
     ap.add_argument("--event-steps", type=int, default=128, help="extra steps timed per kernel launch with HIP events")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the multi-rank path on one GPU)")
+    ap.add_argument("--device-index", type=int, default=-1, help="GPU index of this rank (default LOCAL_RANK)")
+    ap.add_argument("--adv-allgather", action="store_true", help="N > 1: every 16 steps all-gather + standardise a [16*B] float32 advantage tensor (the PPO-side collective)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     args = ap.parse_args()
@@ -135,17 +140,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    dev_index = local_rank if args.device_index < 0 else args.device_index
+    torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(args.backend)
 
     from pcbenv import named_config
     from pcbenv.batched_env import BatchedPlacementEnv
     cfg = named_config(args.config, args.reward)
     B = args.envs or {"c1": 1, "c2": 1024, "c3": 4096, "c4": 4096, "c5": 8192}[args.config]
-    env = BatchedPlacementEnv(cfg, B, device=f"cuda:{local_rank}", queue_depth=args.queue_depth,
+    env = BatchedPlacementEnv(cfg, B, device=f"cuda:{dev_index}", queue_depth=args.queue_depth,
                               run_seed=args.run_seed, first_env_index=rank * B, incremental_obs=args.incremental,
                               auto_reset=(args.loop == "fused"), threads_per_env=args.threads_per_env)
     t_gen = time.perf_counter()
@@ -180,17 +189,27 @@ def main():
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
+    chunk = max(1, args.chunk) if args.loop == "fused" else 1
+    chunk_actions = torch.empty((chunk, B, 3), dtype=torch.int32, device=env.device) if chunk > 1 else None
     t0 = time.perf_counter()
     ev_region[0].record()
-    for k in range(args.steps):
-        one_step(args.warmup + k)
+    if chunk > 1:
+        for k in range(0, args.steps, chunk):
+            env.rollout_steps(args.warmup + k, min(chunk, args.steps - k), out=chunk_actions)
+    else:
+        adv = torch.randn(16 * B, device=env.device) if (dist and args.adv_allgather) else None
+        for k in range(args.steps):
+            one_step(args.warmup + k)
+            if adv is not None and k % 16 == 15:
+                from pcbenv.distributed import normalize_advantages
+                adv_n = normalize_advantages(adv if args.backend == "nccl" else adv.cpu(), "all_gather")  # noqa: F841
     ev_region[1].record()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=env.device)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=env.device if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     step_kernel_ms = None
@@ -244,7 +263,7 @@ def main():
                 "data": "synthetic (reference-exact instance generator, seeds 1000003*run_seed+env; uniform legal actions drawn on device)",
                 "config": {"workload": f"{args.config}: {cfg.height}x{cfg.width} grid, {cfg.max_num_components} components, "
                                        f"{cfg.max_total_pins} pins, reward={args.reward}", "envs_per_gpu": B,
-                           "queue_depth": args.queue_depth, "incremental_obs": bool(args.incremental), "loop": args.loop,
+                           "queue_depth": args.queue_depth, "incremental_obs": bool(args.incremental), "loop": args.loop, "steps_per_host_call": chunk,
                            "instance_generation_s": round(t_gen, 2)},
                 "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(line), flush=True)

@@ -177,6 +177,12 @@ int pcbenv_sample_actions(pcbenv *env, int32_t *actions_dev, int32_t action_form
 int pcbenv_step_sampled(pcbenv *env, int32_t *actions_out_dev, int32_t action_format, uint64_t seed,
                         uint64_t first_env_index, uint64_t step_index, void *stream);
 
+/* num_steps consecutive pcbenv_step_sampled calls issued from C (no per-step host round trip): step t draws with
+ * step_index0 + t and records its actions in actions_out_dev[t] (int32 [num_steps, num_envs, 3] or
+ * [num_steps, num_envs] for the flat format).  Intended with PCBENV_FLAG_AUTO_RESET. */
+int pcbenv_rollout_sampled(pcbenv *env, int32_t *actions_out_dev, int32_t action_format, int32_t num_steps,
+                           uint64_t seed, uint64_t first_env_index, uint64_t step_index0, void *stream);
+
 /* Native host-side instance generator: stream `seed` (< 2^32) yields, record by record (wire format above), the
  * instances the reference's generate_instances() draws after `np.random.seed(seed); random.seed(seed)`
  * (dummy_env_rectangular_pin_spatial.py:931-1212, :1408-1443; rect/pin siblings).  Not for PCBENV_SQUARE.

@@ -1344,3 +1344,16 @@ extern "C" int pcbenv_set_state(pcbenv *env, const void *host_src, void *stream)
     HIP_TRY(env, hipStreamSynchronize((hipStream_t)stream));
     return PCBENV_OK;
 }
+
+extern "C" int pcbenv_rollout_sampled(pcbenv *env, int32_t *actions_out_dev, int32_t fmt, int32_t num_steps,
+                                      uint64_t seed, uint64_t first_env_index, uint64_t step_index0, void *stream) {
+    int rc = pre_launch(env);
+    if (rc) return rc;
+    if (!actions_out_dev || num_steps < 0) return fail(env, PCBENV_EINVAL, "bad rollout arguments");
+    if (fmt != PCBENV_ACTION_TUPLE && fmt != PCBENV_ACTION_FLAT) return fail(env, PCBENV_EINVAL, "unknown action format");
+    const size_t per_step = (size_t)env->dp.B * (fmt == PCBENV_ACTION_TUPLE ? 3 : 1);
+    for (int t = 0; t < num_steps; t++)
+        dispatch_step(env, actions_out_dev + per_step * (size_t)t, fmt, 1, seed, first_env_index, step_index0 + (uint64_t)t, (hipStream_t)stream);
+    HIP_TRY(env, hipGetLastError());
+    return PCBENV_OK;
+}

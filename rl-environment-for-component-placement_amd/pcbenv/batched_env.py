@@ -238,6 +238,16 @@ class BatchedPlacementEnv:
             self.first_env_index, int(step_index), self._stream()), self._h)
         return self.obs, self.reward, self.done, self.info, out
 
+    def rollout_steps(self, step_index0: int, num_steps: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """`num_steps` fused sample+step launches issued from C in one call (use with auto_reset=True);
+        returns the actions taken, int32 [num_steps, B, 3]."""
+        if out is None:
+            out = torch.empty((num_steps, self.num_envs, 3), dtype=torch.int32, device=self.device)
+        _lib.check(self._L.pcbenv_rollout_sampled(
+            self._h, out.data_ptr(), _lib.ACTION_TUPLE, int(num_steps), self.run_seed, self.first_env_index,
+            int(step_index0), self._stream()), self._h)
+        return out
+
     # -- checkpoint / resume ------------------------------------------------------------------
     def state_dict(self) -> dict:
         """Library state + observation tensors (host copies).  The reference never serialises env state

@@ -287,3 +287,19 @@ def test_ppo_loop_runs_and_uses_only_legal_actions():
     tr.update(tr.collect())
     assert len(tr.returns) == 2 and all(-11.0 < r < 0.0 for r in tr.returns)  # worst case (invalid action) is -10.6
     env.close()
+
+
+def test_rollout_steps_equals_single_steps():
+    cfg = named_config("c2")
+    envs = [BatchedPlacementEnv(cfg, 32, queue_depth=2, run_seed=5, auto_reset=True) for _ in range(2)]
+    for e in envs:
+        e.generate_instances(); e.reset()
+    acts = envs[0].rollout_steps(0, 20).cpu().numpy()
+    for t in range(20):
+        _, _, _, _, a = envs[1].rollout_step(t)
+        assert np.array_equal(a.cpu().numpy(), acts[t])
+    for k in envs[0].obs:
+        assert torch.equal(envs[0].obs[k], envs[1].obs[k])
+    assert torch.equal(envs[0].reward, envs[1].reward) and torch.equal(envs[0].done, envs[1].done)
+    for e in envs:
+        e.close()

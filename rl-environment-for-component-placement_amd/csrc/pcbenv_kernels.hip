@@ -34,7 +34,7 @@ typedef unsigned long long u64;
 struct DevParams {
     int kind, H, W, WW, O, C, P, N, K, mp, mh, mw, F, pinRows, catW, B, Q;
     int reward_type, beam_width, component_n;
-    unsigned flags;
+    unsigned flags, bind_gen;
     double w_wl, w_int, max_wl, max_int, wl_norm, int_norm, area;
     long long stateStride, instStride;
     int offOcc, offVm, offComps, offPins;   // byte offsets inside a state block
@@ -50,7 +50,8 @@ struct __attribute__((aligned(16))) EnvHdr {
     unsigned episode;                // completed resets
     unsigned qcursor;                // next queue slot
     unsigned flag;                   // LDS scratch word for workgroup-wide any()
-    unsigned pad[3];
+    unsigned pad[2];                 // (pad[0..2] double as the broadcast slot of the fused sampler)
+    unsigned feat_gen;               // bind generation for which the pin-feature tensors hold only this env's rows
 };
 static_assert(sizeof(EnvHdr) == HDR_BYTES, "header size");
 
@@ -200,15 +201,18 @@ __device__ inline bool is_intersect(double x1, double y1, double x2, double y2, 
 // ---- routes -------------------------------------------------------------------------------------
 // A route is kept as one segment slot per pin q (slots of net n are nstart[n]..nstart[n+1]-1, so slots are
 // net-major like the reference's route lists); act[q] = 1 if the slot carries a segment.
-struct SegView { double *X1, *Y1, *X2, *Y2, *D, *cen; int *act, *nstart, *pre; };
-#define SEG_LDS_BYTES(P) ((5 * (P) + 2 * PCBENV_MAX_NETS) * 8 + (2 * (P) + PCBENV_MAX_NETS + 4) * 4)
+struct SegView { double *X1, *Y1, *X2, *Y2, *D, *A, *DX, *DY, *cen; int *act, *nstart, *pre; unsigned short *pairs; };
+#define PAIR_BUF 128  // per-wavefront compaction buffer of candidate (i, j) pairs
+#define SEG_LDS_BYTES(P) ((8 * (P) + 2 * PCBENV_MAX_NETS) * 8 + (2 * (P) + PCBENV_MAX_NETS + 4) * 4 + 4 * PAIR_BUF * 2)
 __device__ inline SegView seg_view(double *seg, int P) {
     SegView v;
     v.X1 = seg; v.Y1 = seg + P; v.X2 = seg + 2 * P; v.Y2 = seg + 3 * P; v.D = seg + 4 * P;
-    v.cen = seg + 5 * P;                              // cx[MAX_NETS], cy[MAX_NETS]
+    v.A = seg + 5 * P; v.DX = seg + 6 * P; v.DY = seg + 7 * P;  // per segment: x1*y2 - y1*x2, x1 - x2, y1 - y2
+    v.cen = seg + 8 * P;                              // cx[MAX_NETS], cy[MAX_NETS]
     v.act = (int *)(v.cen + 2 * PCBENV_MAX_NETS);     // [P]
     v.nstart = v.act + P;                             // [nnets + 1]
     v.pre = v.nstart + PCBENV_MAX_NETS + 2;           // [P + 1] prefix of pair counts
+    v.pairs = (unsigned short *)(v.pre + P + 2);      // [4 wavefronts][PAIR_BUF]
     return v;
 }
 
@@ -247,10 +251,43 @@ __device__ inline void build_centroid_segments(const SegView &v, const EnvHdr *h
 
 // S:629-651 find_num_intersection + S:704-722 find_wirelength over the slots.  The (segment, later-net segment)
 // pairs are flattened over the 64 lanes; the wirelength is summed sequentially in route order (bit-exact).
+// is_intersect (S:653-702) on two slots, with the per-segment terms hoisted: the operations and their order are
+// exactly the reference's -- (x1*y2 - y1*x2), (x1 - x2), (y1 - y2) are sub-expressions of its formulas.
+__device__ inline bool slots_intersect(const SegView &v, int i, int j) {
+    const double x1 = v.X1[i], y1 = v.Y1[i], x2 = v.X2[i], y2 = v.Y2[i];
+    const double x3 = v.X1[j], y3 = v.Y1[j], x4 = v.X2[j], y4 = v.Y2[j];
+    if ((x1 == x3 && y1 == y3) || (x1 == x4 && y1 == y4) || (x2 == x3 && y2 == y3) || (x2 == x4 && y2 == y4)) return true;
+    const double dxi = v.DX[i], dyi = v.DY[i], dxj = v.DX[j], dyj = v.DY[j];
+    const double det = dxi * dyj - dyi * dxj;
+    if (det == 0) return false;
+    const double a = v.A[i], b = v.A[j];
+    const double x = (a * dxj - dxi * b) / det;
+    const double y = (a * dyj - dyi * b) / det;
+    return fmin(x1, x2) <= x && x <= fmax(x1, x2) && fmin(x3, x4) <= x && x <= fmax(x3, x4) &&
+           fmin(y1, y2) <= y && y <= fmax(y1, y2) && fmin(y3, y4) <= y && y <= fmax(y3, y4);
+}
+// Exact pre-filter: if the closed x- (or y-) extents of the two segments are disjoint, no x (y) can lie in both,
+// so the reference's final range test fails whatever the computed intersection point is (a shared end point,
+// its only early "True", puts a common point in both extents).  Saves the two float64 divisions.
+__device__ inline bool extents_overlap(const SegView &v, int i, int j) {
+    const double x1 = v.X1[i], y1 = v.Y1[i], x2 = v.X2[i], y2 = v.Y2[i];
+    const double x3 = v.X1[j], y3 = v.Y1[j], x4 = v.X2[j], y4 = v.Y2[j];
+    return fmax(fmin(x1, x2), fmin(x3, x4)) <= fmin(fmax(x1, x2), fmax(x3, x4)) &&
+           fmax(fmin(y1, y2), fmin(y3, y4)) <= fmin(fmax(y1, y2), fmax(y3, y4));
+}
+
+// S:629-651 find_num_intersection + S:704-722 find_wirelength over the slots.  The (segment, later-net segment)
+// pairs are flattened over the lanes; each wavefront first filters its pairs by extent overlap, compacts the
+// survivors into an LDS buffer (ballot + prefix) and runs the full test on dense batches of 64.  The wirelength
+// is summed sequentially in route order (bit-exact with the reference's python float loop).
 __device__ inline void count_and_length(const SegView &v, const EnvHdr *hdr, const PinRec *pins, int lane,
                                         double *wirelength, int *nintersections) {
     const int np = hdr->npins;
     int *total_cnt = v.nstart + PCBENV_MAX_NETS + 1;  // spare slot behind nstart[0..MAX_NETS]
+    for (int q = lane; q < np; q += NT) {
+        const double x1 = v.X1[q], y1 = v.Y1[q], x2 = v.X2[q], y2 = v.Y2[q];
+        v.A[q] = x1 * y2 - y1 * x2; v.DX[q] = x1 - x2; v.DY[q] = y1 - y2;
+    }
     if (lane == 0) {
         int acc = 0;
         for (int i = 0; i < np; i++) { v.pre[i] = acc; if (v.act[i]) acc += np - v.nstart[pins[i].net + 1]; }
@@ -259,15 +296,32 @@ __device__ inline void count_and_length(const SegView &v, const EnvHdr *hdr, con
     }
     lds_sync();
     const int total = v.pre[np];
-    int cnt = 0;
-    for (int t = lane; t < total; t += NT) {
-        int lo = 0, hi = np;  // largest i with pre[i] <= t (and a non-empty range)
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (v.pre[mid] <= t) lo = mid; else hi = mid; }
-        const int i = lo, j = v.nstart[pins[i].net + 1] + (t - v.pre[i]);
-        if (v.act[j] && is_intersect(v.X1[i], v.Y1[i], v.X2[i], v.Y2[i], v.X1[j], v.Y1[j], v.X2[j], v.Y2[j])) cnt++;
+    const int wl_lane = lane & 63;
+    volatile unsigned short *buf = v.pairs + (lane >> 6) * PAIR_BUF;  // wave-synchronous: written and read by different lanes
+    int cnt = 0, nbuf = 0, i = 0;
+    for (int base = 0; base < total; base += NT) {  // wave-uniform trip count
+        const int t = base + lane;
+        bool pass = false;
+        int j = 0;
+        if (t < total) {
+            while (v.pre[i + 1] <= t) i++;  // pre[] is non-decreasing and t only grows: amortised O(1)
+            j = v.nstart[pins[i].net + 1] + (t - v.pre[i]);
+            pass = v.act[j] && extents_overlap(v, i, j);
+        }
+        const u64 ball = __ballot(pass);
+        if (pass) buf[nbuf + __popcll(ball & ((1ull << wl_lane) - 1ull))] = (unsigned short)(i | (j << 8));
+        nbuf += __popcll(ball);
+        if (nbuf >= WAVE) {  // a dense batch of 64 candidates
+            const unsigned short pr = buf[wl_lane];
+            const unsigned short keep = buf[WAVE + wl_lane];
+            if (slots_intersect(v, pr & 0xFF, pr >> 8)) cnt++;
+            nbuf -= WAVE;
+            if (wl_lane < nbuf) buf[wl_lane] = keep;
+        }
     }
+    if (wl_lane < nbuf) { const unsigned short pr = buf[wl_lane]; if (slots_intersect(v, pr & 0xFF, pr >> 8)) cnt++; }
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
-    if ((lane & 63) == 0 && cnt) atomicAdd(total_cnt, cnt);
+    if (wl_lane == 0 && cnt) atomicAdd(total_cnt, cnt);
     lds_sync();
     double wl = 0.0;
     for (int q = 0; q < np; q++) if (v.act[q]) wl += v.D[q];
@@ -702,6 +756,26 @@ __global__ __launch_bounds__(WAVE) void k_sample(DevParams p, int *__restrict__ 
 template <int KIND, int WW> __device__ inline void reset_env(const DevParams &p, Lds &l, int e, int lane) {
     const int H = p.H, W = p.W, HW = H * W;
     lds_sync();
+    // The float64 pin-feature tensors are maintained row-wise (a step rewrites only the placed component's
+    // rows), so a reset clears just the rows the finished episode used -- unless these buffers have not been
+    // initialised for this environment yet (first reset after pcbenv_bind_buffers): then a full zero fill.
+    bool rows_cleared = false;
+    if ((KIND == PCBENV_PIN || KIND == PCBENV_SPATIAL) && l.hdr->feat_gen == p.bind_gen) {
+        for (int q = lane; q < l.hdr->npins; q += NT) {
+            const PinRec pr = l.pins[q];
+            const int row = KIND == PCBENV_SPATIAL ? (pr.id & PIN_ID_MASK) : pr.comp * p.mp + (pr.id & PIN_ID_MASK);
+            if (p.buf.all_pins_num_feature) {
+                double *f = p.buf.all_pins_num_feature + ((size_t)e * p.pinRows + row) * 4;
+                f[0] = 0.0; f[1] = 0.0; f[2] = 0.0; f[3] = 0.0;
+            }
+            if (p.buf.all_pins_cat_feature) {
+                double *f = p.buf.all_pins_cat_feature + ((size_t)e * p.pinRows + row) * p.catW;
+                f[0] = 0.0; if (KIND == PCBENV_SPATIAL) f[1] = 0.0;
+            }
+        }
+        rows_cleared = true;
+    }
+    lds_sync();
     for (int i = lane; i < H * WW; i += NT) l.occ[i] = 0ull;
     if (KIND != PCBENV_SQUARE) {
         const unsigned slot = l.hdr->qcursor % (unsigned)p.Q;
@@ -775,15 +849,16 @@ template <int KIND, int WW> __device__ inline void reset_env(const DevParams &p,
             for (int c = lane; c < p.C; c += NT) cm[c] = c < nc ? 1.0 : 0.0;
         }
         if (KIND == PCBENV_PIN || KIND == PCBENV_SPATIAL) {
-            if (p.buf.all_pins_num_feature) {
+            if (!rows_cleared && p.buf.all_pins_num_feature) {
                 double *f = p.buf.all_pins_num_feature + (size_t)e * p.pinRows * 4;
                 for (int i = lane; i < p.pinRows * 4; i += NT) f[i] = 0.0;
             }
-            if (p.buf.all_pins_cat_feature) {
+            if (!rows_cleared && p.buf.all_pins_cat_feature) {
                 double *f = p.buf.all_pins_cat_feature + (size_t)e * p.pinRows * p.catW;
                 for (int i = lane; i < p.pinRows * p.catW; i += NT)
                     f[i] = (KIND == PCBENV_SPATIAL && i >= (p.pinRows - 1) * p.catW) ? -1.0 : 0.0;  // S:1520
             }
+            if (lane == 0) l.hdr->feat_gen = p.bind_gen;
             __syncthreads();  // also orders this thread block's global stores (zero fill before the row writes)
             __threadfence_block();
             for (int q = lane; q < np; q += NT) {
@@ -825,8 +900,8 @@ __global__ __launch_bounds__(64 * NW) void k_reset(DevParams p, const unsigned c
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int e = blockIdx.x, lane = threadIdx.x;
     if (mask && !mask[e]) return;
+    load_state(smem, p, e, lane);  // cursor / episode survive; the old pins tell which feature rows to clear
     Lds l = carve(smem, p);
-    if (lane == 0) *l.hdr = *(const EnvHdr *)(p.state + (size_t)e * p.stateStride);  // cursor / episode survive
     reset_env<KIND, WW>(p, l, e, lane);
     if (lane == 0) {
         p.buf.reward[e] = 0.0;
@@ -857,13 +932,13 @@ __global__ __launch_bounds__(64 * NW) void k_step(DevParams p, int *__restrict__
         if (lane < WAVE) {  // wave 0 draws, the others take the result from LDS
             sample_action(l.vm, p, (int)first_env + e, lane, seed, step_index, &o, &x, &y);
             if (lane == 0) {
-                l.hdr->pad[0] = (unsigned)o; l.hdr->pad[1] = (unsigned)x; l.hdr->pad[2] = (unsigned)y;
+                l.hdr->pad[0] = (unsigned)o; l.hdr->pad[1] = (unsigned)x; l.hdr->flag = (unsigned)y;
                 if (fmt == PCBENV_ACTION_FLAT) actions[e] = o * HW + x * W + y;
                 else { actions[3 * e] = o; actions[3 * e + 1] = x; actions[3 * e + 2] = y; }
             }
         }
         lds_sync();
-        o = (int)l.hdr->pad[0]; x = (int)l.hdr->pad[1]; y = (int)l.hdr->pad[2];
+        o = (int)l.hdr->pad[0]; x = (int)l.hdr->pad[1]; y = (int)l.hdr->flag;
     } else if (fmt == PCBENV_ACTION_FLAT) {  // utils/environment/env_wrappers.py:80-98, :184-199
         const int a = actions[e];
         if (a < 0 || a >= p.O * HW) { o = -1; x = y = 0; }
@@ -1180,6 +1255,7 @@ extern "C" int pcbenv_bind_buffers(pcbenv *env, const pcbenv_buffers *b) {
     if (!is_pin_kind(k)) { env->dp.buf.all_pins_num_feature = 0; env->dp.buf.all_pins_cat_feature = 0; env->dp.buf.info = 0; }
     if (k != PCBENV_RECT) env->dp.buf.component_mask = 0;
     if (k == PCBENV_SQUARE) { env->dp.buf.all_components_feature = 0; env->dp.buf.placement_mask = 0; }
+    env->dp.bind_gen += 1;  // feature tensors of these buffers are uninitialised: the next reset of each env fills them
     env->bound = true;
     return PCBENV_OK;
 }

@@ -303,3 +303,20 @@ def test_rollout_steps_equals_single_steps():
     assert torch.equal(envs[0].reward, envs[1].reward) and torch.equal(envs[0].done, envs[1].done)
     for e in envs:
         e.close()
+
+
+def test_ragged_and_maximum_shapes_vs_oracle():
+    """Edge shapes: non-square grids whose width is not a multiple of 16 / spans two 64-bit words, a 1-component
+    instance range, and the largest configuration the HIP path accepts (128x128, 64 components, 256 pins, 16 nets
+    of 16 pins, beam width 4)."""
+    _oracle_rollout(EnvConfig.spatial(7, 100, 5, 5, 2, 7, 2, 7, 10, 1, 1, 4, 6, 2, "both", 2, 0.5), 12, episodes=2, p_bad=0.05)
+    _oracle_rollout(EnvConfig.pin(100, 9, 5, 5, 2, 6, 2, 6, 12, 3, 2, 4, 6, 2, "centroid", 2, 0.5), 12, episodes=2, p_bad=0.05)
+    _oracle_rollout(EnvConfig.rect(33, 65, 1, 9, 1, 9, 40, 5), 8, episodes=2, p_bad=0.02)
+    _oracle_rollout(EnvConfig.square(3, 130 - 2, 3), 4, episodes=1, p_bad=0.0)
+    big = EnvConfig.spatial(128, 128, 9, 9, 2, 8, 2, 8, 64, 40, 8, 16, 16, 4, "both", 4, 0.5)
+    assert big.max_total_pins == 256
+    _oracle_rollout(big, 3, episodes=1, queue_depth=1, p_bad=0.0)
+    _oracle_rollout(big, 3, episodes=1, queue_depth=1, p_bad=0.0, threads=64, auto_reset=True, fused=True)
+    # a grid completely filled by one component, and 1x1 components
+    _oracle_rollout(EnvConfig.rect(4, 4, 4, 4, 4, 4, 2, 2), 4, episodes=2, p_bad=0.0)
+    _oracle_rollout(EnvConfig.rect(6, 6, 1, 1, 1, 1, 3, 1), 4, episodes=2, p_bad=0.1)

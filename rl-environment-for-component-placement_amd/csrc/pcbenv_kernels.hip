@@ -41,7 +41,6 @@ struct DevParams {
     int ldsHf, ldsCls, ldsSeg, ldsBytes;    // byte offsets of LDS scratch behind the state mirror
     unsigned char *state, *queue;
     pcbenv_buffers buf;
-    unsigned char *pending;                 // [B] 1 = routed reward still to be computed (beam / both)
 };
 
 // per-environment header at the start of a state block
@@ -339,14 +338,28 @@ __device__ inline void route_centroid(const DevParams &p, const EnvHdr *hdr, con
 }
 
 // ---- beam-search routing (S:1273-1286 pin_outlier, S:1303-1369 beam_search, S:1371-1406) -----------------
-// beam_search sorts `points_to_visit - visited` with a stable sort, so equal-distance neighbours keep the
-// iteration order of that temporary CPython set.  The order is a pure function of the tuple hashes and of
-// Objects/setobject.c's open-addressing table (SURVEY.md trap T2); modelled here for <= 15 points per net.
+// beam_search keeps, per popped path, the beam_width nearest unvisited points of
+// `sorted(points_to_visit - visited, key=distance)`.  Python's sort is stable, so neighbours at equal distance
+// keep the iteration order of that temporary CPython set -- a pure function of the tuple hashes and of
+// Objects/setobject.c's open-addressing table (SURVEY.md trap T2).  That order can only change WHICH points are
+// kept when the beam_width-th and the next distance tie (the order among kept neighbours is irrelevant: heapq
+// pops by (priority, path), not by insertion).  So the set model below runs only on such boundary ties.
+// One lane per net; all per-net scratch lives in LDS (no private-memory arrays -> no scratch segment).
 #define CS_EMPTY 0xFF
 #define CS_DUMMY 0xFE
 #define BS_MAXPTS (PCBENV_MAX_PINS_PER_NET - 1)
-#define BS_MAXQ (PCBENV_MAX_BEAM_WIDTH * PCBENV_MAX_BEAM_WIDTH)
-struct CSet { int mask, fill, used; unsigned char t[32]; };
+struct CSet { int mask, fill, used; unsigned char t[32]; int pad; };  // 48 bytes
+struct BsEntry { double prio; unsigned short visited; unsigned char len; unsigned char path[BS_MAXPTS + 1]; unsigned char pad[4]; };  // path[0] = start (0xFF)
+static_assert(sizeof(BsEntry) == 32 && sizeof(CSet) == 48, "beam LDS records");
+#define BEAM_LDS_PER_NET(k) (64 * (k) * (k) + 16 * 8 + 16 + 2 * 48)
+#define BEAM_LDS_BYTES(nets, k) ((nets) * BEAM_LDS_PER_NET(k))
+
+// points to visit of one net: the net's pins without the start pin `st`
+struct NetPts {
+    const PinRec *p; int st;
+    __device__ int x(int i) const { return p[i < st ? i : i + 1].abs_x; }
+    __device__ int y(int i) const { return p[i < st ? i : i + 1].abs_y; }
+};
 
 __device__ inline u64 tuple_hash2(int x, int y) {  // Objects/tupleobject.c (xxHash-style), hash(int) == int
     const u64 P1 = 11400714785074694791ull, P2 = 14029467366897019727ull, P5 = 2870177450012600261ull;
@@ -356,19 +369,19 @@ __device__ inline u64 tuple_hash2(int x, int y) {  // Objects/tupleobject.c (xxH
     acc += 2ull ^ (P5 ^ 3527539ull);
     return acc == ~0ull ? 1546275796ull : acc;
 }
-__device__ inline void cs_init(CSet &s, int size) {
-    s.mask = size - 1; s.fill = 0; s.used = 0;
-    for (int i = 0; i < 32; i++) s.t[i] = CS_EMPTY;
+__device__ inline void cs_init(CSet *s, int size) {
+    s->mask = size - 1; s->fill = 0; s->used = 0;
+    for (int i = 0; i < 32; i++) s->t[i] = CS_EMPTY;
 }
 // first unused slot on the probe sequence of `hash` (set_insert_clean / the miss path of set_add_entry)
-__device__ inline int cs_probe_unused(const CSet &s, u64 hash, int *freeslot) {
-    const unsigned mask = (unsigned)s.mask;
+__device__ inline int cs_probe_unused(const CSet *s, u64 hash, int *freeslot) {
+    const unsigned mask = (unsigned)s->mask;
     u64 perturb = hash;
     unsigned i = (unsigned)hash & mask;
     for (;;) {
         const unsigned probes = (i + 9u <= mask) ? 9u : 0u;
         for (unsigned k = 0; k <= probes; k++) {
-            const unsigned char c = s.t[i + k];
+            const unsigned char c = s->t[i + k];
             if (c == CS_EMPTY) return (int)(i + k);
             if (c == CS_DUMMY && freeslot) *freeslot = (int)(i + k);
         }
@@ -376,68 +389,77 @@ __device__ inline int cs_probe_unused(const CSet &s, u64 hash, int *freeslot) {
         i = (unsigned)(((u64)i * 5u + 1u + perturb) & mask);
     }
 }
-__device__ inline void cs_resize(CSet &s, int minused, const signed char *px, const signed char *py) {
+// set_table_resize: re-insert the active keys in old slot order (the old table is copied to `tmp` first)
+__device__ inline void cs_resize(CSet *s, CSet *tmp, int minused, const NetPts &pt) {
     int newsize = 8;
     while (newsize <= minused) newsize <<= 1;
-    CSet old = s;
+    *tmp = *s;
     cs_init(s, newsize);
-    for (int i = 0; i <= old.mask; i++)
-        if (old.t[i] < CS_DUMMY) s.t[cs_probe_unused(s, tuple_hash2(px[old.t[i]], py[old.t[i]]), 0)] = old.t[i];
-    s.fill = s.used = old.used;
+    for (int i = 0; i <= tmp->mask; i++)
+        if (tmp->t[i] < CS_DUMMY) s->t[cs_probe_unused(s, tuple_hash2(pt.x(tmp->t[i]), pt.y(tmp->t[i])), 0)] = tmp->t[i];
+    s->fill = s->used = tmp->used;
 }
-__device__ inline void cs_add(CSet &s, int key, const signed char *px, const signed char *py) {
+__device__ inline void cs_add(CSet *s, CSet *tmp, int key, const NetPts &pt) {
     int freeslot = -1;
-    const int slot = cs_probe_unused(s, tuple_hash2(px[key], py[key]), &freeslot);
-    if (freeslot >= 0) { s.t[freeslot] = (unsigned char)key; s.used++; return; }
-    s.t[slot] = (unsigned char)key; s.fill++; s.used++;
-    if (s.fill * 5 >= s.mask * 3) cs_resize(s, s.used * 4, px, py);
+    const int slot = cs_probe_unused(s, tuple_hash2(pt.x(key), pt.y(key)), &freeslot);
+    if (freeslot >= 0) { s->t[freeslot] = (unsigned char)key; s->used++; return; }
+    s->t[slot] = (unsigned char)key; s->fill++; s->used++;
+    if (s->fill * 5 >= s->mask * 3) cs_resize(s, tmp, s->used * 4, pt);
 }
-__device__ inline void cs_discard(CSet &s, int key, const signed char *px, const signed char *py) {
-    const unsigned mask = (unsigned)s.mask;
-    const u64 hash = tuple_hash2(px[key], py[key]);
+__device__ inline void cs_discard(CSet *s, int key, const NetPts &pt) {
+    const unsigned mask = (unsigned)s->mask;
+    const u64 hash = tuple_hash2(pt.x(key), pt.y(key));
     u64 perturb = hash;
     unsigned i = (unsigned)hash & mask;
     for (;;) {
         const unsigned probes = (i + 9u <= mask) ? 9u : 0u;
         for (unsigned k = 0; k <= probes; k++) {
-            const unsigned char c = s.t[i + k];
+            const unsigned char c = s->t[i + k];
             if (c == CS_EMPTY) return;
-            if (c == (unsigned char)key) { s.t[i + k] = CS_DUMMY; s.used--; return; }
+            if (c == (unsigned char)key) { s->t[i + k] = CS_DUMMY; s->used--; return; }
         }
         perturb >>= 5;
         i = (unsigned)(((u64)i * 5u + 1u + perturb) & mask);
     }
 }
-// iteration order of `A - visited` (set_difference): copy-and-discard when len(A) >> 2 > len(visited)
-__device__ inline int cs_difference_order(const CSet &A, int m, unsigned visited, const signed char *px,
-                                          const signed char *py, unsigned char *order) {
-    CSet R;
+// Iteration order of `set(points) - visited` (set_difference: copy-and-discard when len(A) >> 2 > len(visited),
+// else a fresh set filled in A's slot order).  A and R are LDS tables; `order` receives point indices.
+__device__ inline int cs_difference_order(CSet *A, CSet *R, int m, unsigned visited, const NetPts &pt, unsigned char *order) {
+    // points_to_visit = set(points): inserted in list order.  R doubles as the resize temporary while A is built.
+    cs_init(A, 8);
+    for (int i = 0; i < m; i++) cs_add(A, R, i, pt);
     if ((m >> 2) > __popc(visited)) {
         cs_init(R, 8);
-        if (m * 5 >= R.mask * 3) { int ns = 8; while (ns <= 2 * m) ns <<= 1; cs_init(R, ns); }
-        if (R.mask == A.mask) { R = A; }  // set_merge: same size, no dummies -> the table is copied as is
+        if (m * 5 >= R->mask * 3) { int ns = 8; while (ns <= 2 * m) ns <<= 1; cs_init(R, ns); }
+        if (R->mask == A->mask) { *R = *A; }  // set_merge: same size, no dummies -> the table is copied as is
         else {
-            for (int i = 0; i <= A.mask; i++)
-                if (A.t[i] < CS_DUMMY) R.t[cs_probe_unused(R, tuple_hash2(px[A.t[i]], py[A.t[i]]), 0)] = A.t[i];
-            R.fill = R.used = A.used;
+            for (int i = 0; i <= A->mask; i++)
+                if (A->t[i] < CS_DUMMY) R->t[cs_probe_unused(R, tuple_hash2(pt.x(A->t[i]), pt.y(A->t[i])), 0)] = A->t[i];
+            R->fill = R->used = A->used;
         }
-        for (int k = 0; k < m; k++) if (visited >> k & 1u) cs_discard(R, k, px, py);
-        if (R.fill - R.used > R.mask / 4) cs_resize(R, R.used * 4, px, py);
+        for (int k = 0; k < m; k++) if (visited >> k & 1u) cs_discard(R, k, pt);
+        // "if more than 1/4th are dummies, resize them away" cannot trigger for m <= 15 (<= 2 dummies, mask >= 15)
     } else {
+        // fresh result set filled in A's slot order: collect the survivors first, after which A is free to
+        // serve as the temporary of R's set_table_resize (5th insert: 8 -> 32 slots)
+        int ns = 0;
+        for (int i = 0; i <= A->mask; i++)
+            if (A->t[i] < CS_DUMMY && !(visited >> A->t[i] & 1u)) order[ns++] = A->t[i];
         cs_init(R, 8);
-        for (int i = 0; i <= A.mask; i++)
-            if (A.t[i] < CS_DUMMY && !(visited >> A.t[i] & 1u)) cs_add(R, A.t[i], px, py);
+        for (int i = 0; i < ns; i++) cs_add(R, A, order[i], pt);
     }
     int n = 0;
-    for (int i = 0; i <= R.mask; i++) if (R.t[i] < CS_DUMMY) order[n++] = R.t[i];
+    for (int i = 0; i <= R->mask; i++) if (R->t[i] < CS_DUMMY) order[n++] = R->t[i];
     return n;
 }
 
-struct BsEntry { double prio; unsigned visited; unsigned char len; unsigned char path[BS_MAXPTS + 1]; };  // path[0] = start (0xFF)
-
 // One net, one lane: fills the net's slots [s, s+cnt) of the segment view with the beam route.
-__device__ inline void beam_route_net(const SegView &v, const PinRec *pins, int s, int cnt, int k) {
-    signed char px[BS_MAXPTS + 1], py[BS_MAXPTS + 1];
+// `scratch` = this net's BEAM_LDS_PER_NET(k) bytes of LDS.
+__device__ inline void beam_route_net(const SegView &v, const PinRec *pins, int s, int cnt, int k, unsigned char *scratch) {
+    BsEntry *queue = (BsEntry *)scratch, *next = queue + k * k;
+    double *dist = (double *)(scratch + 64 * k * k);
+    unsigned char *order = (unsigned char *)(dist + 16);
+    CSet *A = (CSet *)(order + 16), *R = A + 1;
     const double cx = v.cen[pins[s].net], cy = v.cen[PCBENV_MAX_NETS + pins[s].net];
     int st = 0; double bd = 0.0;  // pin_outlier: first arg-max of the distance to the centroid
     for (int i = 0; i < cnt; i++) {
@@ -445,22 +467,17 @@ __device__ inline void beam_route_net(const SegView &v, const PinRec *pins, int 
         if (i == 0 || d > bd) { bd = d; st = i; }
     }
     const int sx = pins[s + st].abs_x, sy = pins[s + st].abs_y;
-    int m = 0;
-    for (int i = 0; i < cnt; i++) if (i != st) { px[m] = pins[s + i].abs_x; py[m] = pins[s + i].abs_y; m++; }
-    CSet A;
-    cs_init(A, 8);
-    for (int i = 0; i < m; i++) cs_add(A, i, px, py);
+    const int m = cnt - 1;
+    const NetPts pt{pins + s, st};
     const unsigned all = (1u << m) - 1u;
-    BsEntry qa[BS_MAXQ], qb[BS_MAXQ];
-    BsEntry *queue = qa, *next = qb;
     int qn = 1;
     queue[0].prio = 0.0; queue[0].visited = 0; queue[0].len = 1; queue[0].path[0] = 0xFF;
-    const BsEntry *result = 0;
-    while (!result) {
+    int result = -1;  // index into `queue`
+    while (result < 0) {
         int nn = 0;
         unsigned taken = 0;
         const int pops = k < qn ? k : qn;
-        for (int t = 0; t < pops && !result; t++) {
+        for (int t = 0; t < pops && result < 0; t++) {
             int best = -1;  // heappop: minimum (priority, path) of what is left
             for (int i = 0; i < qn; i++) {
                 if (taken >> i & 1u) continue;
@@ -472,8 +489,8 @@ __device__ inline void beam_route_net(const SegView &v, const PinRec *pins, int 
                     less = a.len < b.len;
                     const int n = a.len < b.len ? a.len : b.len;
                     for (int j = 0; j < n; j++) {
-                        const int ax = a.path[j] == 0xFF ? sx : px[a.path[j]], ay = a.path[j] == 0xFF ? sy : py[a.path[j]];
-                        const int bx = b.path[j] == 0xFF ? sx : px[b.path[j]], by = b.path[j] == 0xFF ? sy : py[b.path[j]];
+                        const int ax = a.path[j] == 0xFF ? sx : pt.x(a.path[j]), ay = a.path[j] == 0xFF ? sy : pt.y(a.path[j]);
+                        const int bx = b.path[j] == 0xFF ? sx : pt.x(b.path[j]), by = b.path[j] == 0xFF ? sy : pt.y(b.path[j]);
                         if (ax != bx) { less = ax < bx; break; }
                         if (ay != by) { less = ay < by; break; }
                     }
@@ -482,39 +499,68 @@ __device__ inline void beam_route_net(const SegView &v, const PinRec *pins, int 
             }
             taken |= 1u << best;
             const BsEntry &e = queue[best];
-            if (e.visited == all) { result = &e; break; }
+            if (e.visited == all) { result = best; break; }
             const int cur = e.path[e.len - 1];
-            const int ux = cur == 0xFF ? sx : px[cur], uy = cur == 0xFF ? sy : py[cur];
-            unsigned char order[BS_MAXPTS + 1];
-            double dist[BS_MAXPTS + 1];
-            const int cntn = cs_difference_order(A, m, e.visited, px, py, order);
-            for (int i = 0; i < cntn; i++) dist[i] = norm2((double)(ux - px[order[i]]), (double)(uy - py[order[i]]));
-            for (int i = 1; i < cntn; i++) {  // sorted(key=distance): stable
-                const unsigned char o = order[i]; const double d = dist[i];
-                int j = i - 1;
+            const int ux = cur == 0xFF ? sx : pt.x(cur), uy = cur == 0xFF ? sy : pt.y(cur);
+            // unvisited points by ascending distance (index order among ties for now)
+            int cntn = 0;
+            for (int i = 0; i < m; i++) {
+                if (e.visited >> i & 1u) continue;
+                const double d = norm2((double)(ux - pt.x(i)), (double)(uy - pt.y(i)));
+                int j = cntn - 1;
                 while (j >= 0 && dist[j] > d) { order[j + 1] = order[j]; dist[j + 1] = dist[j]; j--; }
-                order[j + 1] = o; dist[j + 1] = d;
+                order[j + 1] = (unsigned char)i; dist[j + 1] = d;
+                cntn++;
+            }
+            if (cntn > k && dist[k - 1] == dist[k]) {  // boundary tie: the CPython set order decides who is kept
+                const int nset = cs_difference_order(A, R, m, e.visited, pt, order);
+                for (int i = 0; i < nset; i++) dist[i] = norm2((double)(ux - pt.x(order[i])), (double)(uy - pt.y(order[i])));
+                for (int i = 1; i < nset; i++) {  // sorted(key=distance): stable
+                    const unsigned char o = order[i]; const double d = dist[i];
+                    int j = i - 1;
+                    while (j >= 0 && dist[j] > d) { order[j + 1] = order[j]; dist[j + 1] = dist[j]; j--; }
+                    order[j + 1] = o; dist[j + 1] = d;
+                }
             }
             const int take = cntn < k ? cntn : k;
             for (int i = 0; i < take; i++) {
                 BsEntry &q = next[nn++];
                 q = e;
                 q.path[q.len++] = order[i];
-                q.visited |= 1u << order[i];
+                q.visited |= (unsigned short)(1u << order[i]);
                 q.prio = e.prio + dist[i];
             }
         }
-        if (!result) { BsEntry *tmp = queue; queue = next; next = tmp; qn = nn; if (qn == 0) break; }
+        if (result < 0) { BsEntry *tmp = queue; queue = next; next = tmp; qn = nn; if (qn == 0) break; }
     }
     for (int i = 0; i < cnt; i++) v.act[s + i] = 0;
-    if (!result) return;
-    for (int i = 0; i + 1 < result->len; i++) {
-        const int a = result->path[i], b = result->path[i + 1];
-        const double x1 = a == 0xFF ? sx : px[a], y1 = a == 0xFF ? sy : py[a];
-        const double x2 = b == 0xFF ? sx : px[b], y2 = b == 0xFF ? sy : py[b];
+    if (result < 0) return;
+    const BsEntry &r = queue[result];
+    for (int i = 0; i + 1 < r.len; i++) {
+        const int a = r.path[i], b = r.path[i + 1];
+        const double x1 = a == 0xFF ? sx : pt.x(a), y1 = a == 0xFF ? sy : pt.y(a);
+        const double x2 = b == 0xFF ? sx : pt.x(b), y2 = b == 0xFF ? sy : pt.y(b);
         v.X1[s + i] = x1; v.Y1[s + i] = y1; v.X2[s + i] = x2; v.Y2[s + i] = y2;
         v.D[s + i] = norm2(x1 - x2, y1 - y2);
         v.act[s + i] = 1;
+    }
+}
+
+// beam (and, for "both", centroid) routes of the terminal state -> wirelength, #intersections of the chosen route
+__device__ inline void route_beam_or_both(const DevParams &p, const EnvHdr *hdr, const PinRec *pins, double *seg,
+                                          int lane, double *wirelength, int *nintersections) {
+    const SegView v = seg_view(seg, p.P);
+    unsigned char *beam = (unsigned char *)seg + SEG_LDS_BYTES(p.P);
+    net_offsets_and_centroids(v, hdr, pins, lane);
+    for (int n = lane; n < hdr->nnets; n += NT)
+        beam_route_net(v, pins, v.nstart[n], v.nstart[n + 1] - v.nstart[n], p.beam_width, beam + (size_t)n * BEAM_LDS_PER_NET(p.beam_width));
+    lds_sync();
+    count_and_length(v, hdr, pins, lane, wirelength, nintersections);
+    if (p.reward_type == PCBENV_REWARD_BOTH) {  // S:609-627 lowest_num_intersections: ties keep the beam route
+        double wc; int kc;
+        build_centroid_segments(v, hdr, pins, lane);
+        count_and_length(v, hdr, pins, lane, &wc, &kc);
+        if (kc < *nintersections) { *nintersections = kc; *wirelength = wc; }
     }
 }
 
@@ -664,30 +710,27 @@ template <int KIND> __device__ inline void write_pin_num(const DevParams &p, int
     f[0] = pr.rel_x; f[1] = pr.rel_y; f[2] = pr.abs_x; f[3] = pr.abs_y;
 }
 
-// Terminal reward (S:793-929 find_reward).  beam / both routes are left to k_reward_routes.
-// Returns true when the routed reward is deferred to k_reward_routes (beam / both).
-template <int KIND>
-__device__ inline bool terminal_reward(const DevParams &p, Lds &l, int e, int lane) {
+// Terminal reward (S:793-929 find_reward), all three reward types, inside the step kernel.
+// ROUTES = false compiles the beam-search code out (reward_type centroid: what every shipped reference config uses).
+template <int KIND, bool ROUTES>
+__device__ inline void terminal_reward(const DevParams &p, Lds &l, int e, int lane) {
     const bool placed_all = l.hdr->cur < 0;
     double reward, wl, ni;
     if (!placed_all) {  // S:853-863 worst case: the upper bounds, normalised (spatial: twice, quirk Q3)
         reward = -p.w_wl * (p.max_wl / p.wl_norm) - p.w_int * (p.max_int / p.int_norm);
         wl = p.max_wl; ni = p.max_int;
-    } else if (p.reward_type == PCBENV_REWARD_CENTROID) {
+    } else {
         double wsum; int cnt;
-        route_centroid(p, l.hdr, l.pins, l.seg, lane, &wsum, &cnt);
+        if (!ROUTES) route_centroid(p, l.hdr, l.pins, l.seg, lane, &wsum, &cnt);
+        else route_beam_or_both(p, l.hdr, l.pins, l.seg, lane, &wsum, &cnt);
         wl = wsum / p.wl_norm;
         ni = (double)cnt / p.int_norm;
         reward = -1 * (p.w_wl * wl + p.w_int * ni);
-    } else {
-        if (lane == 0) p.pending[e] = 1;
-        return true;
     }
     if (lane == 0) {
         p.buf.reward[e] = reward;
         if (p.buf.info) { p.buf.info[2 * e] = wl; p.buf.info[2 * e + 1] = ni; }
     }
-    return false;
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -907,7 +950,6 @@ __global__ __launch_bounds__(64 * NW) void k_reset(DevParams p, const unsigned c
         p.buf.reward[e] = 0.0;
         p.buf.done[e] = 0;
         if (p.buf.info) { p.buf.info[2 * e] = nan(""); p.buf.info[2 * e + 1] = nan(""); }
-        if (p.pending) p.pending[e] = 0;
     }
     store_state(smem, p, e, lane);
 }
@@ -917,7 +959,7 @@ __global__ __launch_bounds__(64 * NW) void k_reset(DevParams p, const unsigned c
 //   sampled != 0: the action is drawn here (same generator as k_sample) and written to `actions`
 //   PCBENV_FLAG_AUTO_RESET: a terminal transition is followed, in the same launch, by the reset
 // ----------------------------------------------------------------------------------------------
-template <int KIND, int WW, int NW>
+template <int KIND, int WW, int NW, bool ROUTES>
 __global__ __launch_bounds__(64 * NW) void k_step(DevParams p, int *__restrict__ actions, int fmt, int sampled,
                                                u64 seed, u64 first_env, u64 step_index) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -953,15 +995,13 @@ __global__ __launch_bounds__(64 * NW) void k_step(DevParams p, int *__restrict__
     if (valid) valid = (l.vm[(o & 1) * plane + x * WW + (y >> 6)] >> (y & 63)) & 1ull;
 
     if (lane == 0 && p.buf.info) { p.buf.info[2 * e] = nan(""); p.buf.info[2 * e + 1] = nan(""); }
-    if (lane == 0 && p.pending) p.pending[e] = 0;
     lds_sync();
 
-    bool deferred = false;
     if (!valid) {  // terminal transition, state and observations unchanged (quirk Q8 iii)
         if (lane == 0) p.buf.done[e] = 1;
         if (KIND == PCBENV_SQUARE || KIND == PCBENV_RECT) { if (lane == 0) p.buf.reward[e] = 0.0; }
-        else deferred = terminal_reward<KIND>(p, l, e, lane);
-        if (auto_reset && !deferred) { reset_env<KIND, WW>(p, l, e, lane); store_state(smem, p, e, lane); }
+        else terminal_reward<KIND, ROUTES>(p, l, e, lane);
+        if (auto_reset) { reset_env<KIND, WW>(p, l, e, lane); store_state(smem, p, e, lane); }
         return;
     }
 
@@ -1015,51 +1055,16 @@ __global__ __launch_bounds__(64 * NW) void k_step(DevParams p, int *__restrict__
     // costs a double write).
     const bool inc = (p.flags & PCBENV_FLAG_INCREMENTAL_OBS) != 0;
     const int r0 = inc ? x : 0, r1 = inc ? min(x + ph, H) : H;
-    const bool routed_later = (KIND == PCBENV_PIN || KIND == PCBENV_SPATIAL) && p.reward_type != PCBENV_REWARD_CENTROID;
-    const bool skip_emit = auto_reset && !routed_later && KIND != PCBENV_SQUARE && l.hdr->cur < 0;
+    const bool skip_emit = auto_reset && KIND != PCBENV_SQUARE && l.hdr->cur < 0;
     const bool any = mask_and_emit<KIND, WW>(p, l, e, lane, !skip_emit, r0, r1);
     if (KIND == PCBENV_SPATIAL && !skip_emit) emit_pin_grid<WW>(p, l, e, lane, r0, r1);
     const bool done = KIND == PCBENV_SQUARE ? !any : (l.hdr->cur < 0 || !any);  // S:1856-1869
     if (lane == 0) p.buf.done[e] = done ? 1 : 0;
     if (KIND == PCBENV_SQUARE || KIND == PCBENV_RECT) { if (lane == 0) p.buf.reward[e] = 1.0; }
     else if (!done) { if (lane == 0) p.buf.reward[e] = 0.0; }
-    else deferred = terminal_reward<KIND>(p, l, e, lane);
-    if (done && auto_reset && !deferred) reset_env<KIND, WW>(p, l, e, lane);  // rewrites every observation
+    else terminal_reward<KIND, ROUTES>(p, l, e, lane);
+    if (done && auto_reset) reset_env<KIND, WW>(p, l, e, lane);  // rewrites every observation
     store_state(smem, p, e, lane);
-}
-
-// ----------------------------------------------------------------------------------------------
-// routed terminal reward for reward_type beam / both (S:866-886, :905-928); runs after k_step, only for
-// environments whose step left `pending` set (all components placed).  One lane per net for the beam search.
-// ----------------------------------------------------------------------------------------------
-template <int KIND, int WW, int NW>
-__global__ __launch_bounds__(64 * NW) void k_reward_routes(DevParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int e = blockIdx.x, lane = threadIdx.x;
-    if (!p.pending[e]) return;
-    load_state(smem, p, e, lane);
-    Lds l = carve(smem, p);
-    const SegView v = seg_view(l.seg, p.P);
-    net_offsets_and_centroids(v, l.hdr, l.pins, lane);
-    for (int n = lane; n < l.hdr->nnets; n += NT)
-        beam_route_net(v, l.pins, v.nstart[n], v.nstart[n + 1] - v.nstart[n], p.beam_width);
-    lds_sync();
-    double wsum; int cnt;
-    count_and_length(v, l.hdr, l.pins, lane, &wsum, &cnt);
-    if (p.reward_type == PCBENV_REWARD_BOTH) {  // S:609-627 lowest_num_intersections: ties keep the beam route
-        double wc; int kc;
-        build_centroid_segments(v, l.hdr, l.pins, lane);
-        count_and_length(v, l.hdr, l.pins, lane, &wc, &kc);
-        if (kc < cnt) { cnt = kc; wsum = wc; }
-    }
-    const double wl = wsum / p.wl_norm, ni = (double)cnt / p.int_norm;
-    const double reward = -1 * (p.w_wl * wl + p.w_int * ni);
-    if (lane == 0) {
-        p.buf.reward[e] = reward;
-        if (p.buf.info) { p.buf.info[2 * e] = wl; p.buf.info[2 * e + 1] = ni; }
-        p.pending[e] = 0;
-    }
-    if (p.flags & PCBENV_FLAG_AUTO_RESET) { reset_env<KIND, WW>(p, l, e, lane); store_state(smem, p, e, lane); }
 }
 
 // ==============================================================================================
@@ -1216,6 +1221,7 @@ extern "C" int pcbenv_create(const pcbenv_config *cfg, int device, pcbenv **out)
     d.ldsSeg = d.ldsCls;
     {
         int cls = c.kind == PCBENV_SPATIAL ? d.H * d.W : 0, seg = is_pin_kind(c.kind) ? SEG_LDS_BYTES(d.P) : 0;
+        if (is_pin_kind(c.kind) && c.reward_type != PCBENV_REWARD_CENTROID) seg += BEAM_LDS_BYTES(c.max_num_nets, c.reward_beam_width);
         d.ldsBytes = align16(d.ldsCls + (cls > seg ? cls : seg));
     }
     // threads per environment: one wave up to 64x64 cells of output per plane, four waves above
@@ -1223,15 +1229,13 @@ extern "C" int pcbenv_create(const pcbenv_config *cfg, int device, pcbenv **out)
                    : ((long long)c.height * c.width * (c.kind == PCBENV_SPATIAL ? d.K + 5 : 5) > 64 * 1024 ? 256 : 64);
     if (hipSetDevice(device) != hipSuccess) { int r = fail(0, PCBENV_EHIP, "hipSetDevice failed (no such device?)"); delete env; return r; }
     size_t sbytes = (size_t)d.stateStride * d.B, qbytes = (size_t)d.instStride * d.B * d.Q;
-    if (hipMalloc((void **)&d.state, sbytes) != hipSuccess || hipMalloc((void **)&d.queue, qbytes ? qbytes : 16) != hipSuccess ||
-        hipMalloc((void **)&d.pending, (size_t)d.B) != hipSuccess) {
+    if (hipMalloc((void **)&d.state, sbytes) != hipSuccess || hipMalloc((void **)&d.queue, qbytes ? qbytes : 16) != hipSuccess ) {
         int r = fail(0, PCBENV_EHIP, "hipMalloc failed");
         pcbenv_destroy(env);
         return r;
     }
     hipMemset(d.state, 0, sbytes);
     hipMemset(d.queue, 0, qbytes ? qbytes : 16);
-    hipMemset(d.pending, 0, (size_t)d.B);
     hipDeviceSynchronize();
     *out = env;
     return PCBENV_OK;
@@ -1242,7 +1246,6 @@ extern "C" void pcbenv_destroy(pcbenv *env) {
     hipSetDevice(env->device);
     if (env->dp.state) hipFree(env->dp.state);
     if (env->dp.queue) hipFree(env->dp.queue);
-    if (env->dp.pending) hipFree(env->dp.pending);
     delete env;
 }
 
@@ -1312,13 +1315,15 @@ template <int KIND> static int launch_reset(pcbenv *env, const uint8_t *mask, hi
 template <int KIND> static int launch_step(pcbenv *env, int *actions, int fmt, int sampled, u64 seed, u64 first_env,
                                            u64 step_index, hipStream_t s) {
     const DevParams &d = env->dp;
-#define LAUNCH_STEP(WW_, NW_) hipLaunchKernelGGL((k_step<KIND, WW_, NW_>), dim3(d.B), dim3(64 * NW_), d.ldsBytes, s, d, actions, fmt, sampled, seed, first_env, step_index)
-    if (d.WW == 1) { if (env->threads == 64) LAUNCH_STEP(1, 1); else LAUNCH_STEP(1, 4); }
-    else { if (env->threads == 64) LAUNCH_STEP(2, 1); else LAUNCH_STEP(2, 4); }
-    if ((KIND == PCBENV_PIN || KIND == PCBENV_SPATIAL) && env->cfg.reward_type != PCBENV_REWARD_CENTROID) {
-#define LAUNCH_ROUTES(WW_, NW_) hipLaunchKernelGGL((k_reward_routes<KIND, WW_, NW_>), dim3(d.B), dim3(64 * NW_), d.ldsBytes, s, d)
-        if (d.WW == 1) { if (env->threads == 64) LAUNCH_ROUTES(1, 1); else LAUNCH_ROUTES(1, 4); }
-        else { if (env->threads == 64) LAUNCH_ROUTES(2, 1); else LAUNCH_ROUTES(2, 4); }
+#define LAUNCH_STEP(WW_, NW_, RT_) hipLaunchKernelGGL((k_step<KIND, WW_, NW_, RT_>), dim3(d.B), dim3(64 * NW_), d.ldsBytes, s, d, actions, fmt, sampled, seed, first_env, step_index)
+    constexpr bool PINK = (KIND == PCBENV_PIN || KIND == PCBENV_SPATIAL);
+    const bool routes = PINK && env->cfg.reward_type != PCBENV_REWARD_CENTROID;
+    if (routes) {
+        if (d.WW == 1) { if (env->threads == 64) LAUNCH_STEP(1, 1, PINK); else LAUNCH_STEP(1, 4, PINK); }
+        else { if (env->threads == 64) LAUNCH_STEP(2, 1, PINK); else LAUNCH_STEP(2, 4, PINK); }
+    } else {
+        if (d.WW == 1) { if (env->threads == 64) LAUNCH_STEP(1, 1, false); else LAUNCH_STEP(1, 4, false); }
+        else { if (env->threads == 64) LAUNCH_STEP(2, 1, false); else LAUNCH_STEP(2, 4, false); }
     }
     return 0;
 }
@@ -1400,14 +1405,13 @@ extern "C" const uint64_t *pcbenv_mask_bits(const pcbenv *env, int64_t *env_stri
 }
 
 extern "C" int64_t pcbenv_state_bytes(const pcbenv *env) {
-    return env ? (int64_t)env->dp.stateStride * env->dp.B + env->dp.B : 0;
+    return env ? (int64_t)env->dp.stateStride * env->dp.B : 0;
 }
 extern "C" int pcbenv_get_state(pcbenv *env, void *host_dst, void *stream) {
     if (!env || !host_dst) return fail(env, PCBENV_EINVAL, "null argument");
     HIP_TRY(env, hipSetDevice(env->device));
     const size_t sb = (size_t)env->dp.stateStride * env->dp.B;
     HIP_TRY(env, hipMemcpyAsync(host_dst, env->dp.state, sb, hipMemcpyDeviceToHost, (hipStream_t)stream));
-    HIP_TRY(env, hipMemcpyAsync((char *)host_dst + sb, env->dp.pending, (size_t)env->dp.B, hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY(env, hipStreamSynchronize((hipStream_t)stream));
     return PCBENV_OK;
 }
@@ -1416,7 +1420,6 @@ extern "C" int pcbenv_set_state(pcbenv *env, const void *host_src, void *stream)
     HIP_TRY(env, hipSetDevice(env->device));
     const size_t sb = (size_t)env->dp.stateStride * env->dp.B;
     HIP_TRY(env, hipMemcpyAsync(env->dp.state, host_src, sb, hipMemcpyHostToDevice, (hipStream_t)stream));
-    HIP_TRY(env, hipMemcpyAsync(env->dp.pending, (const char *)host_src + sb, (size_t)env->dp.B, hipMemcpyHostToDevice, (hipStream_t)stream));
     HIP_TRY(env, hipStreamSynchronize((hipStream_t)stream));
     return PCBENV_OK;
 }

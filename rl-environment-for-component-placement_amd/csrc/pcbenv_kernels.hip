@@ -200,17 +200,22 @@ __device__ inline bool is_intersect(double x1, double y1, double x2, double y2, 
 // ---- routes -------------------------------------------------------------------------------------
 // A route is kept as one segment slot per pin q (slots of net n are nstart[n]..nstart[n+1]-1, so slots are
 // net-major like the reference's route lists); act[q] = 1 if the slot carries a segment.
-struct SegView { double *X1, *Y1, *X2, *Y2, *D, *A, *DX, *DY, *cen; int *act, *nstart, *pre; unsigned short *pairs; };
+struct SegView { double *X1, *Y1, *X2, *Y2, *D, *A, *DX, *DY, *cen; int *act, *nstart, *pre; unsigned short *pairs; unsigned char *beam; };
 #define PAIR_BUF 128  // per-wavefront compaction buffer of candidate (i, j) pairs
-#define SEG_LDS_BYTES(P) ((8 * (P) + 2 * PCBENV_MAX_NETS) * 8 + (2 * (P) + PCBENV_MAX_NETS + 4) * 4 + 4 * PAIR_BUF * 2)
+// [segments X1 Y1 X2 Y2 D | centroids | act nstart] then a zone used only by the pair count (A DX DY pre pairs),
+// which the beam search -- finished before the count starts -- overlays with its per-net scratch.
+#define SEG_FIXED_BYTES(P) ((5 * (P) + 2 * PCBENV_MAX_NETS) * 8 + ((P) + PCBENV_MAX_NETS + 4) * 4)
+#define SEG_COUNT_BYTES(P) (3 * (P) * 8 + ((P) + 2) * 4 + 4 * PAIR_BUF * 2)
+#define SEG_LDS_BYTES(P, beam) (((SEG_FIXED_BYTES(P) + 7) & ~7) + ((beam) > SEG_COUNT_BYTES(P) ? (beam) : SEG_COUNT_BYTES(P)))
 __device__ inline SegView seg_view(double *seg, int P) {
     SegView v;
     v.X1 = seg; v.Y1 = seg + P; v.X2 = seg + 2 * P; v.Y2 = seg + 3 * P; v.D = seg + 4 * P;
-    v.A = seg + 5 * P; v.DX = seg + 6 * P; v.DY = seg + 7 * P;  // per segment: x1*y2 - y1*x2, x1 - x2, y1 - y2
-    v.cen = seg + 8 * P;                              // cx[MAX_NETS], cy[MAX_NETS]
+    v.cen = seg + 5 * P;                              // cx[MAX_NETS], cy[MAX_NETS]
     v.act = (int *)(v.cen + 2 * PCBENV_MAX_NETS);     // [P]
-    v.nstart = v.act + P;                             // [nnets + 1]
-    v.pre = v.nstart + PCBENV_MAX_NETS + 2;           // [P + 1] prefix of pair counts
+    v.nstart = v.act + P;                             // [nnets + 1] (+ spare counter slot)
+    v.beam = (unsigned char *)seg + ((SEG_FIXED_BYTES(P) + 7) & ~7);
+    v.A = (double *)v.beam; v.DX = v.A + P; v.DY = v.A + 2 * P;  // per segment: x1*y2 - y1*x2, x1 - x2, y1 - y2
+    v.pre = (int *)(v.A + 3 * P);                     // [P + 1] prefix of pair counts
     v.pairs = (unsigned short *)(v.pre + P + 2);      // [4 wavefronts][PAIR_BUF]
     return v;
 }
@@ -349,16 +354,41 @@ __device__ inline void route_centroid(const DevParams &p, const EnvHdr *hdr, con
 #define CS_DUMMY 0xFE
 #define BS_MAXPTS (PCBENV_MAX_PINS_PER_NET - 1)
 struct CSet { int mask, fill, used; unsigned char t[32]; int pad; };  // 48 bytes
-struct BsEntry { double prio; unsigned short visited; unsigned char len; unsigned char path[BS_MAXPTS + 1]; unsigned char pad[4]; };  // path[0] = start (0xFF)
+// one partial path of the beam: four 64-bit words so that queue traffic is wide LDS accesses and the popped
+// entry lives in registers.  meta = visited (bits 0-15) | length (bits 16-23); p0/p1 = the path, one byte per
+// point index (0xFF = the start point).
+struct BsEntry {
+    double prio; u64 meta, p0, p1;
+    __device__ unsigned visited() const { return (unsigned)(meta & 0xFFFFull); }
+    __device__ int len() const { return (int)((meta >> 16) & 0xFFull); }
+    __device__ int at(int j) const { return (int)(((j < 8 ? p0 : p1) >> ((j & 7) * 8)) & 0xFFull); }
+    __device__ void push(int idx) {
+        const int l = len();
+        const u64 b = (u64)(unsigned)idx << ((l & 7) * 8);
+        if (l < 8) p0 |= b; else p1 |= b;
+        meta = (meta & ~(0xFFull << 16)) | ((u64)(l + 1) << 16) | (1ull << idx);
+    }
+};
 static_assert(sizeof(BsEntry) == 32 && sizeof(CSet) == 48, "beam LDS records");
 #define BEAM_LDS_PER_NET(k) (64 * (k) * (k) + 16 * 8 + 16 + 2 * 48)
 #define BEAM_LDS_BYTES(nets, k) ((nets) * BEAM_LDS_PER_NET(k))
 
 // points to visit of one net: the net's pins without the start pin `st`
-struct NetPts {
-    const PinRec *p; int st;
-    __device__ int x(int i) const { return p[i < st ? i : i + 1].abs_x; }
-    __device__ int y(int i) const { return p[i < st ? i : i + 1].abs_y; }
+struct NetPts {  // coordinates packed one byte each into registers (<= 15 points): no LDS round trip per access
+    u64 xs0, xs1, ys0, ys1;
+    __device__ int x(int i) const { return (int)(((i < 8 ? xs0 : xs1) >> ((i & 7) * 8)) & 0xFFull); }
+    __device__ int y(int i) const { return (int)(((i < 8 ? ys0 : ys1) >> ((i & 7) * 8)) & 0xFFull); }
+    __device__ static NetPts load(const PinRec *p, int cnt, int st) {
+        NetPts n{0ull, 0ull, 0ull, 0ull};
+        int m = 0;
+        for (int i = 0; i < cnt; i++) {
+            if (i == st) continue;
+            const u64 x = (u64)(unsigned char)p[i].abs_x << ((m & 7) * 8), y = (u64)(unsigned char)p[i].abs_y << ((m & 7) * 8);
+            if (m < 8) { n.xs0 |= x; n.ys0 |= y; } else { n.xs1 |= x; n.ys1 |= y; }
+            m++;
+        }
+        return n;
+    }
 };
 
 __device__ inline u64 tuple_hash2(int x, int y) {  // Objects/tupleobject.c (xxHash-style), hash(int) == int
@@ -468,52 +498,70 @@ __device__ inline void beam_route_net(const SegView &v, const PinRec *pins, int 
     }
     const int sx = pins[s + st].abs_x, sy = pins[s + st].abs_y;
     const int m = cnt - 1;
-    const NetPts pt{pins + s, st};
+    const NetPts pt = NetPts::load(pins + s, cnt, st);
     const unsigned all = (1u << m) - 1u;
     int qn = 1;
-    queue[0].prio = 0.0; queue[0].visited = 0; queue[0].len = 1; queue[0].path[0] = 0xFF;
-    int result = -1;  // index into `queue`
-    while (result < 0) {
+    { BsEntry e0; e0.prio = 0.0; e0.meta = 1ull << 16; e0.p0 = 0xFFull; e0.p1 = 0ull; queue[0] = e0; }
+    bool found = false;
+    BsEntry res;
+    while (!found) {
         int nn = 0;
         unsigned taken = 0;
         const int pops = k < qn ? k : qn;
-        for (int t = 0; t < pops && result < 0; t++) {
+        for (int t = 0; t < pops && !found; t++) {
             int best = -1;  // heappop: minimum (priority, path) of what is left
+            BsEntry e;
             for (int i = 0; i < qn; i++) {
                 if (taken >> i & 1u) continue;
-                if (best < 0) { best = i; continue; }
-                const BsEntry &a = queue[i], &b = queue[best];
+                const BsEntry a = queue[i];
                 bool less;
-                if (a.prio != b.prio) less = a.prio < b.prio;
-                else {
-                    less = a.len < b.len;
-                    const int n = a.len < b.len ? a.len : b.len;
+                if (best < 0) less = true;
+                else if (a.prio != e.prio) less = a.prio < e.prio;
+                else {  // equal priorities: python compares the path lists of (x, y) tuples
+                    less = a.len() < e.len();
+                    const int n = a.len() < e.len() ? a.len() : e.len();
                     for (int j = 0; j < n; j++) {
-                        const int ax = a.path[j] == 0xFF ? sx : pt.x(a.path[j]), ay = a.path[j] == 0xFF ? sy : pt.y(a.path[j]);
-                        const int bx = b.path[j] == 0xFF ? sx : pt.x(b.path[j]), by = b.path[j] == 0xFF ? sy : pt.y(b.path[j]);
+                        const int pa = a.at(j), pb = e.at(j);
+                        const int ax = pa == 0xFF ? sx : pt.x(pa), ay = pa == 0xFF ? sy : pt.y(pa);
+                        const int bx = pb == 0xFF ? sx : pt.x(pb), by = pb == 0xFF ? sy : pt.y(pb);
                         if (ax != bx) { less = ax < bx; break; }
                         if (ay != by) { less = ay < by; break; }
                     }
                 }
-                if (less) best = i;
+                if (less) { best = i; e = a; }
             }
             taken |= 1u << best;
-            const BsEntry &e = queue[best];
-            if (e.visited == all) { result = best; break; }
-            const int cur = e.path[e.len - 1];
+            if (e.visited() == all) { found = true; res = e; break; }
+            const int cur = e.at(e.len() - 1);
             const int ux = cur == 0xFF ? sx : pt.x(cur), uy = cur == 0xFF ? sy : pt.y(cur);
-            // unvisited points by ascending distance (index order among ties for now)
-            int cntn = 0;
+            // the k+1 nearest unvisited points in registers (ascending distance, index order among equals)
+            double td[PCBENV_MAX_BEAM_WIDTH + 1]; int ti[PCBENV_MAX_BEAM_WIDTH + 1];
+            #pragma unroll
+            for (int q = 0; q <= PCBENV_MAX_BEAM_WIDTH; q++) { td[q] = 0.0; ti[q] = 0; }
+            int nfill = 0, cntn = 0;
             for (int i = 0; i < m; i++) {
-                if (e.visited >> i & 1u) continue;
-                const double d = norm2((double)(ux - pt.x(i)), (double)(uy - pt.y(i)));
-                int j = cntn - 1;
-                while (j >= 0 && dist[j] > d) { order[j + 1] = order[j]; dist[j + 1] = dist[j]; j--; }
-                order[j + 1] = (unsigned char)i; dist[j + 1] = d;
+                if (e.visited() >> i & 1u) continue;
                 cntn++;
+                double cd = norm2((double)(ux - pt.x(i)), (double)(uy - pt.y(i)));
+                int ci = i;
+                bool shifting = false, placed = false;
+                #pragma unroll
+                for (int q = 0; q <= PCBENV_MAX_BEAM_WIDTH; q++) {
+                    if (q > k || placed) continue;
+                    if (q == nfill) { td[q] = cd; ti[q] = ci; placed = true; }
+                    else if (shifting || td[q] > cd) {
+                        const double xd = td[q]; const int xi = ti[q];
+                        td[q] = cd; ti[q] = ci; cd = xd; ci = xi; shifting = true;
+                    }
+                }
+                if (nfill <= k) nfill++;
             }
-            if (cntn > k && dist[k - 1] == dist[k]) {  // boundary tie: the CPython set order decides who is kept
-                const int nset = cs_difference_order(A, R, m, e.visited, pt, order);
+            const int take = cntn < k ? cntn : k;
+            bool tie = false;
+            #pragma unroll
+            for (int q = 1; q <= PCBENV_MAX_BEAM_WIDTH; q++) if (q == k && cntn > k) tie = td[q - 1] == td[q];
+            if (tie) {  // boundary tie: the CPython set order decides who is kept
+                const int nset = cs_difference_order(A, R, m, e.visited(), pt, order);
                 for (int i = 0; i < nset; i++) dist[i] = norm2((double)(ux - pt.x(order[i])), (double)(uy - pt.y(order[i])));
                 for (int i = 1; i < nset; i++) {  // sorted(key=distance): stable
                     const unsigned char o = order[i]; const double d = dist[i];
@@ -521,23 +569,19 @@ __device__ inline void beam_route_net(const SegView &v, const PinRec *pins, int 
                     while (j >= 0 && dist[j] > d) { order[j + 1] = order[j]; dist[j + 1] = dist[j]; j--; }
                     order[j + 1] = o; dist[j + 1] = d;
                 }
-            }
-            const int take = cntn < k ? cntn : k;
-            for (int i = 0; i < take; i++) {
-                BsEntry &q = next[nn++];
-                q = e;
-                q.path[q.len++] = order[i];
-                q.visited |= (unsigned short)(1u << order[i]);
-                q.prio = e.prio + dist[i];
+                for (int i = 0; i < take; i++) { BsEntry q = e; q.push(order[i]); q.prio = e.prio + dist[i]; next[nn++] = q; }
+            } else {
+                #pragma unroll
+                for (int q = 0; q < PCBENV_MAX_BEAM_WIDTH; q++)
+                    if (q < take) { BsEntry w = e; w.push(ti[q]); w.prio = e.prio + td[q]; next[nn++] = w; }
             }
         }
-        if (result < 0) { BsEntry *tmp = queue; queue = next; next = tmp; qn = nn; if (qn == 0) break; }
+        if (!found) { BsEntry *tmp = queue; queue = next; next = tmp; qn = nn; if (qn == 0) break; }
     }
     for (int i = 0; i < cnt; i++) v.act[s + i] = 0;
-    if (result < 0) return;
-    const BsEntry &r = queue[result];
-    for (int i = 0; i + 1 < r.len; i++) {
-        const int a = r.path[i], b = r.path[i + 1];
+    if (!found) return;
+    for (int i = 0; i + 1 < res.len(); i++) {
+        const int a = res.at(i), b = res.at(i + 1);
         const double x1 = a == 0xFF ? sx : pt.x(a), y1 = a == 0xFF ? sy : pt.y(a);
         const double x2 = b == 0xFF ? sx : pt.x(b), y2 = b == 0xFF ? sy : pt.y(b);
         v.X1[s + i] = x1; v.Y1[s + i] = y1; v.X2[s + i] = x2; v.Y2[s + i] = y2;
@@ -550,7 +594,7 @@ __device__ inline void beam_route_net(const SegView &v, const PinRec *pins, int 
 __device__ inline void route_beam_or_both(const DevParams &p, const EnvHdr *hdr, const PinRec *pins, double *seg,
                                           int lane, double *wirelength, int *nintersections) {
     const SegView v = seg_view(seg, p.P);
-    unsigned char *beam = (unsigned char *)seg + SEG_LDS_BYTES(p.P);
+    unsigned char *beam = v.beam;
     net_offsets_and_centroids(v, hdr, pins, lane);
     for (int n = lane; n < hdr->nnets; n += NT)
         beam_route_net(v, pins, v.nstart[n], v.nstart[n + 1] - v.nstart[n], p.beam_width, beam + (size_t)n * BEAM_LDS_PER_NET(p.beam_width));
@@ -1220,8 +1264,8 @@ extern "C" int pcbenv_create(const pcbenv_config *cfg, int device, pcbenv **out)
     d.ldsCls = align16(d.ldsHf + d.H * d.WW * 8);
     d.ldsSeg = d.ldsCls;
     {
-        int cls = c.kind == PCBENV_SPATIAL ? d.H * d.W : 0, seg = is_pin_kind(c.kind) ? SEG_LDS_BYTES(d.P) : 0;
-        if (is_pin_kind(c.kind) && c.reward_type != PCBENV_REWARD_CENTROID) seg += BEAM_LDS_BYTES(c.max_num_nets, c.reward_beam_width);
+        const int beam = (is_pin_kind(c.kind) && c.reward_type != PCBENV_REWARD_CENTROID) ? BEAM_LDS_BYTES(c.max_num_nets, c.reward_beam_width) : 0;
+        int cls = c.kind == PCBENV_SPATIAL ? d.H * d.W : 0, seg = is_pin_kind(c.kind) ? SEG_LDS_BYTES(d.P, beam) : 0;
         d.ldsBytes = align16(d.ldsCls + (cls > seg ? cls : seg));
     }
     // threads per environment: one wave up to 64x64 cells of output per plane, four waves above

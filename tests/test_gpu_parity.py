@@ -320,3 +320,59 @@ def test_ragged_and_maximum_shapes_vs_oracle():
     # a grid completely filled by one component, and 1x1 components
     _oracle_rollout(EnvConfig.rect(4, 4, 4, 4, 4, 4, 2, 2), 4, episodes=2, p_bad=0.0)
     _oracle_rollout(EnvConfig.rect(6, 6, 1, 1, 1, 1, 3, 1), 4, episodes=2, p_bad=0.1)
+
+
+@pytest.mark.parametrize("name,B", [("c3", 4096), ("c4", 4096), ("c5", 8192)])
+def test_full_size_batches(name, B):
+    """BASELINE.json's full batch sizes.  (1) Two independent runs in different modes -- explicit three-call loop
+    with full refresh vs the fused one-launch loop with incremental rows -- must produce identical tensors for
+    every environment at every step (mode-independence at full size).  (2) Size-independent invariants: occupied
+    cells == sum of placed component areas, mask planes 2/3 mirror 0/1, a legal cell is an empty cell, every
+    episode of these configs ends exactly when the last component is placed, pin_grid == one-hot of the pins.
+    (3) A random sample of 96 environments is replayed through the CPU oracle on the recorded actions."""
+    from oracle import oracle as orc
+    cfg = named_config(name)
+    T = cfg.max_num_components + 3
+    a = BatchedPlacementEnv(cfg, B, queue_depth=2, run_seed=11)
+    b = BatchedPlacementEnv(cfg, B, queue_depth=2, run_seed=11, auto_reset=True, incremental_obs=True)
+    packed = a.generate_instances(verify=8)
+    b.generate_instances()
+    a.reset(); b.reset()
+    acts, rews, dones = [], [], []
+    area = None
+    for t in range(T):
+        act = a.sample_actions(t)
+        a.step(act)
+        _, _, _, _, act_b = b.rollout_step(t)
+        assert torch.equal(act, act_b), t
+        assert torch.equal(a.reward, b.reward) and torch.equal(a.done, b.done), t
+        feat = a.obs["all_components_feature"]
+        placed = (feat[:, :, 2] >= 0).double()
+        area = (feat[:, :, 0] * feat[:, :, 1] * placed).sum(dim=1)
+        assert torch.equal(a.obs["grid"].sum(dim=(1, 2)).double(), area), t
+        m = a.obs["action_mask"]
+        assert torch.equal(m[:, 0], m[:, 2]) and torch.equal(m[:, 1], m[:, 3]), t
+        assert int((m[:, 0] & a.obs["grid"]).sum()) == 0 and int((m[:, 1] & a.obs["grid"]).sum()) == 0, t
+        if "pin_grid" in a.obs:
+            pg = a.obs["pin_grid"]
+            assert int(pg.sum(dim=3).max()) <= 1 and torch.equal(pg.sum(dim=3), a.obs["grid"]), t
+        steps_in_ep = t % cfg.max_num_components
+        assert bool((a.done == (1 if steps_in_ep == cfg.max_num_components - 1 else 0)).all()), t
+        acts.append(act.cpu().numpy()); rews.append(a.reward.cpu().numpy()); dones.append(a.done.cpu().numpy())
+        a.reset_done()
+        for k in a.obs:  # after the explicit reset both runs show the same observations again
+            assert torch.equal(a.obs[k], b.obs[k]), (t, k)
+    # oracle replay of a sample
+    rng = np.random.RandomState(0)
+    idx = np.sort(rng.choice(B, 96, replace=False))
+    ob = orc.OracleBatch(cfg, len(idx))
+    cursor = 0
+    ob.reset_packed(packed[0][idx])
+    for t in range(T):
+        r, d, _ = ob.step(acts[t][idx], threads=4)
+        assert np.array_equal(r.view(np.uint64), rews[t][idx].view(np.uint64)), t
+        assert np.array_equal(d, dones[t][idx]), t
+        if d.any():
+            cursor += 1
+            ob.reset_packed(packed[cursor % 2][idx], d.astype(np.uint8))
+    a.close(); b.close()

@@ -116,3 +116,46 @@ def test_env_seed_is_shard_independent():
     B = 4
     all8 = [env_seed(0, i) for i in range(8)]
     assert [env_seed(0, 1 * B + i) for i in range(B)] == all8[4:8]
+
+
+def test_instance_file_roundtrip(tmp_path):
+    from pcbenv import io
+    cfg = named_config("c4")
+    packed = pack_instances(cfg, [InstanceStream(cfg, s).next() for s in range(7)])
+    p = str(tmp_path / "inst.pcbi")
+    io.save_instances(p, cfg, packed)
+    cfg2, back = io.load_instances(p)
+    assert cfg2 == cfg and np.array_equal(back, packed)
+    with open(p, "r+b") as f:
+        f.write(b"XXXX")
+    with pytest.raises(ValueError):
+        io.load_instances(p)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/environment"), reason="reference tree not present (build container only)")
+def test_episode_export_builds_reference_components():
+    """utils/visualization/csv_utils.py:11-25 pickles `components` + `actions`; the export rebuilds those objects
+    with the reference's own classes and must land every pin where the oracle's features say it is."""
+    import sys
+    sys.dont_write_bytecode = True
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [os.path.join(repo, "oracle", "refshim"), "/root/reference"]
+    try:
+        from environment.dummy_env_rectangular_pin_spatial import Component, Pin
+    finally:
+        del sys.path[:2]
+    from oracle import oracle as orc
+    from pcbenv import io
+    meta, cfg, eps = load_case("spatial_small_centroid")
+    e = next(ep for ep in eps if ep.done[len(ep.actions) - 2] and not np.isnan(ep.info[len(ep.actions) - 2, 0]) and len(ep.actions) > 3)
+    valid_actions = e.actions[:e.instance.num_components]
+    comps, acts = io.episode_to_reference_objects(e.instance, valid_actions, Component, Pin)
+    env = orc.OracleEnv(cfg)
+    env.reset(e.instance)
+    for a in valid_actions:
+        obs, _, _, _ = env.step(a)
+    feats = obs["all_pins_num_feature"]
+    for c in comps:
+        assert tuple(c.position) == (obs["all_components_feature"][c.comp_id, 2], obs["all_components_feature"][c.comp_id, 3])
+        for pin in c.pins:
+            assert list(feats[pin.pin_id]) == [pin.relative_x, pin.relative_y, pin.absolute_x, pin.absolute_y]

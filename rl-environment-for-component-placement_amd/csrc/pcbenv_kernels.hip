@@ -125,6 +125,14 @@ template <int WW> __device__ inline Row<WW> hfold(Row<WW> r, int pw) {
     return f;
 }
 
+// 16-byte observation store.  -DPCBENV_NT_STORES: non-temporal (streaming) variant, kept for A/B measurements.
+#ifdef PCBENV_NT_STORES
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+__device__ inline void STORE16(uint4 *p, uint4 v) { __builtin_nontemporal_store(v4u{v.x, v.y, v.z, v.w}, (v4u *)p); }
+#else
+__device__ inline void STORE16(uint4 *p, uint4 v) { *p = v; }
+#endif
+
 // 4 mask bits -> 4 bytes of 0/1
 __device__ inline unsigned expand4(unsigned b) { return (b * 0x00204081u) & 0x01010101u; }
 __device__ inline uint4 expand16(unsigned bits) {
@@ -140,7 +148,7 @@ template <int WW> __device__ inline void emit_plane(unsigned char *dst, const u6
         for (int c = r0 * W / 16 + lane; c < r1 * W / 16; c += NT) {
             int cell = c * 16, r = sh >= 0 ? cell >> sh : cell / W, col = cell - r * W;
             unsigned b = (unsigned)(bits[r * WW + (col >> 6)] >> (col & 63)) & 0xFFFFu;
-            d4[c] = expand16(b);
+            STORE16(d4 + c, expand16(b));
         }
     } else {  // odd widths (the reference's small test grids): byte path
         for (int i = r0 * W + lane; i < r1 * W; i += NT) {
@@ -152,7 +160,7 @@ template <int WW> __device__ inline void emit_plane(unsigned char *dst, const u6
 __device__ inline void emit_zero(unsigned char *dst, long long bytes, int lane) {
     if ((bytes & 15) == 0 && (((uintptr_t)dst) & 15) == 0) {
         uint4 *d4 = (uint4 *)dst;
-        for (long long c = lane; c < bytes / 16; c += NT) d4[c] = make_uint4(0, 0, 0, 0);
+        for (long long c = lane; c < bytes / 16; c += NT) STORE16(d4 + c, make_uint4(0, 0, 0, 0));
     } else {
         for (long long i = lane; i < bytes; i += NT) dst[i] = 0;
     }
@@ -734,7 +742,7 @@ template <int WW> __device__ inline void emit_pin_grid(const DevParams &p, Lds &
                     if (off < 8) lo |= 1ull << (8 * off); else hi |= 1ull << (8 * (off - 8));
                 }
             }
-            d4[c] = make_uint4((unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32));
+            STORE16(d4 + c, make_uint4((unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)));
         }
     } else {
         for (long long i = b0 + lane; i < b1; i += NT) {

@@ -1145,6 +1145,17 @@ static int fail(pcbenv *env, int code, const char *fmt, const char *detail = "")
         if (e_ != hipSuccess) return fail(env, PCBENV_EHIP, #call ": %s", hipGetErrorString(e_)); \
     } while (0)
 
+// Every entry point works on the handle's device and leaves the caller's current device as it found it.
+struct DeviceGuard {
+    int prev = -1; bool ok = true, changed = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) { ok = hipSetDevice(dev) == hipSuccess; changed = ok && prev >= 0; }
+    }
+    ~DeviceGuard() { if (changed) (void)hipSetDevice(prev); }
+};
+#define DEVICE_GUARD(env) DeviceGuard guard_((env)->device); if (!guard_.ok) return fail(env, PCBENV_EHIP, "hipSetDevice failed")
+
 static int align16(long long v) { return (int)((v + 15) & ~15ll); }
 
 extern "C" int pcbenv_abi_version(void) { return PCBENV_ABI_VERSION; }
@@ -1279,7 +1290,8 @@ extern "C" int pcbenv_create(const pcbenv_config *cfg, int device, pcbenv **out)
     // threads per environment: one wave up to 64x64 cells of output per plane, four waves above
     env->threads = c.reserved == 64 || c.reserved == 256 ? c.reserved
                    : ((long long)c.height * c.width * (c.kind == PCBENV_SPATIAL ? d.K + 5 : 5) > 64 * 1024 ? 256 : 64);
-    if (hipSetDevice(device) != hipSuccess) { int r = fail(0, PCBENV_EHIP, "hipSetDevice failed (no such device?)"); delete env; return r; }
+    DeviceGuard guard_(device);
+    if (!guard_.ok) { int r = fail(0, PCBENV_EHIP, "hipSetDevice failed (no such device?)"); delete env; return r; }
     size_t sbytes = (size_t)d.stateStride * d.B, qbytes = (size_t)d.instStride * d.B * d.Q;
     if (hipMalloc((void **)&d.state, sbytes) != hipSuccess || hipMalloc((void **)&d.queue, qbytes ? qbytes : 16) != hipSuccess ) {
         int r = fail(0, PCBENV_EHIP, "hipMalloc failed");
@@ -1295,7 +1307,7 @@ extern "C" int pcbenv_create(const pcbenv_config *cfg, int device, pcbenv **out)
 
 extern "C" void pcbenv_destroy(pcbenv *env) {
     if (!env) return;
-    hipSetDevice(env->device);
+    DeviceGuard guard_(env->device);
     if (env->dp.state) hipFree(env->dp.state);
     if (env->dp.queue) hipFree(env->dp.queue);
     delete env;
@@ -1321,7 +1333,7 @@ extern "C" int pcbenv_load_instances(pcbenv *env, const int32_t *env_ids, int32_
     const DevParams &d = env->dp;
     if (env->cfg.kind == PCBENV_SQUARE) return PCBENV_OK;  // the square env has no instance
     if (slot < 0 || slot >= d.Q || n < 0 || n > d.B) return fail(env, PCBENV_EINVAL, "slot or count out of range");
-    HIP_TRY(env, hipSetDevice(env->device));
+    DEVICE_GUARD(env);
     const long long src_stride = pcbenv_instance_stride(&env->cfg);
     hipStream_t s = (hipStream_t)stream;
     const unsigned char *src = (const unsigned char *)host_tables;
@@ -1391,7 +1403,6 @@ static int dispatch_step(pcbenv *env, int *actions, int fmt, int sampled, u64 se
 static int pre_launch(pcbenv *env) {
     if (!env) return fail(0, PCBENV_EINVAL, "null handle");
     if (!env->bound) return fail(env, PCBENV_ESTATE, "pcbenv_bind_buffers has not been called");
-    HIP_TRY(env, hipSetDevice(env->device));
     return PCBENV_OK;
 }
 
@@ -1399,6 +1410,7 @@ static int check_queue(pcbenv *env);
 extern "C" int pcbenv_reset(pcbenv *env, const uint8_t *mask_dev, void *stream) {
     int rc = pre_launch(env);
     if (rc) return rc;
+    DEVICE_GUARD(env);
     rc = check_queue(env);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
@@ -1421,6 +1433,7 @@ static int check_queue(pcbenv *env) {
 extern "C" int pcbenv_step(pcbenv *env, const int32_t *actions_dev, int32_t fmt, void *stream) {
     int rc = pre_launch(env);
     if (rc) return rc;
+    DEVICE_GUARD(env);
     if (!actions_dev) return fail(env, PCBENV_EINVAL, "null actions");
     if (fmt != PCBENV_ACTION_TUPLE && fmt != PCBENV_ACTION_FLAT) return fail(env, PCBENV_EINVAL, "unknown action format");
     dispatch_step(env, (int *)actions_dev, fmt, 0, 0, 0, 0, (hipStream_t)stream);
@@ -1432,6 +1445,7 @@ extern "C" int pcbenv_step_sampled(pcbenv *env, int32_t *actions_out_dev, int32_
                                    uint64_t first_env_index, uint64_t step_index, void *stream) {
     int rc = pre_launch(env);
     if (rc) return rc;
+    DEVICE_GUARD(env);
     if (!actions_out_dev) return fail(env, PCBENV_EINVAL, "null actions");
     if (fmt != PCBENV_ACTION_TUPLE && fmt != PCBENV_ACTION_FLAT) return fail(env, PCBENV_EINVAL, "unknown action format");
     dispatch_step(env, actions_out_dev, fmt, 1, seed, first_env_index, step_index, (hipStream_t)stream);
@@ -1443,7 +1457,7 @@ extern "C" int pcbenv_sample_actions(pcbenv *env, int32_t *actions_dev, int32_t 
                                      uint64_t first_env_index, uint64_t step_index, void *stream) {
     if (!env || !actions_dev) return fail(env, PCBENV_EINVAL, "null argument");
     if (fmt != PCBENV_ACTION_TUPLE && fmt != PCBENV_ACTION_FLAT) return fail(env, PCBENV_EINVAL, "unknown action format");
-    HIP_TRY(env, hipSetDevice(env->device));
+    DEVICE_GUARD(env);
     hipLaunchKernelGGL(k_sample, dim3(env->dp.B), dim3(WAVE), 0, (hipStream_t)stream, env->dp, actions_dev, fmt,
                        (u64)seed, (u64)first_env_index, (u64)step_index);
     HIP_TRY(env, hipGetLastError());
@@ -1461,7 +1475,7 @@ extern "C" int64_t pcbenv_state_bytes(const pcbenv *env) {
 }
 extern "C" int pcbenv_get_state(pcbenv *env, void *host_dst, void *stream) {
     if (!env || !host_dst) return fail(env, PCBENV_EINVAL, "null argument");
-    HIP_TRY(env, hipSetDevice(env->device));
+    DEVICE_GUARD(env);
     const size_t sb = (size_t)env->dp.stateStride * env->dp.B;
     HIP_TRY(env, hipMemcpyAsync(host_dst, env->dp.state, sb, hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY(env, hipStreamSynchronize((hipStream_t)stream));
@@ -1469,7 +1483,7 @@ extern "C" int pcbenv_get_state(pcbenv *env, void *host_dst, void *stream) {
 }
 extern "C" int pcbenv_set_state(pcbenv *env, const void *host_src, void *stream) {
     if (!env || !host_src) return fail(env, PCBENV_EINVAL, "null argument");
-    HIP_TRY(env, hipSetDevice(env->device));
+    DEVICE_GUARD(env);
     const size_t sb = (size_t)env->dp.stateStride * env->dp.B;
     HIP_TRY(env, hipMemcpyAsync(env->dp.state, host_src, sb, hipMemcpyHostToDevice, (hipStream_t)stream));
     HIP_TRY(env, hipStreamSynchronize((hipStream_t)stream));
@@ -1480,6 +1494,7 @@ extern "C" int pcbenv_rollout_sampled(pcbenv *env, int32_t *actions_out_dev, int
                                       uint64_t seed, uint64_t first_env_index, uint64_t step_index0, void *stream) {
     int rc = pre_launch(env);
     if (rc) return rc;
+    DEVICE_GUARD(env);
     if (!actions_out_dev || num_steps < 0) return fail(env, PCBENV_EINVAL, "bad rollout arguments");
     if (fmt != PCBENV_ACTION_TUPLE && fmt != PCBENV_ACTION_FLAT) return fail(env, PCBENV_EINVAL, "unknown action format");
     const size_t per_step = (size_t)env->dp.B * (fmt == PCBENV_ACTION_TUPLE ? 3 : 1);

@@ -376,3 +376,64 @@ def test_full_size_batches(name, B):
             cursor += 1
             ob.reset_packed(packed[cursor % 2][idx], d.astype(np.uint8))
     a.close(); b.close()
+
+
+def test_flat_actions_equal_tuple_actions():
+    """PCBENV_ACTION_FLAT (utils/environment/env_wrappers.py:80-98, :184-199) decodes to the same transition as the
+    tuple format, including out-of-range flat indices (invalid -> terminal)."""
+    for name in ("c1", "c2", "c4"):
+        cfg = named_config(name)
+        B = 24
+        envs = [BatchedPlacementEnv(cfg, B, queue_depth=2, run_seed=6) for _ in range(2)]
+        for e in envs:
+            e.generate_instances(); e.reset()
+        O, H, W = cfg.num_orientations, cfg.height, cfg.width
+        rng = np.random.RandomState(1)
+        for t in range(2 * max(cfg.max_num_components, 4)):
+            a = envs[0].sample_actions(t)
+            flat = (a[:, 0] * H + a[:, 1]) * W + a[:, 2] if O > 1 else a[:, 1] * W + a[:, 2]
+            flat = flat.clone()
+            bad = torch.from_numpy(rng.rand(B) < 0.05).to(flat.device)
+            a = a.clone()
+            a[bad] = torch.tensor([0, H, 0], dtype=torch.int32, device=a.device)     # row out of range
+            flat[bad] = O * H * W + 3                                                 # flat index out of range
+            envs[0].step(a)
+            envs[1].step(flat)
+            for k in envs[0].obs:
+                assert torch.equal(envs[0].obs[k], envs[1].obs[k]), (name, t, k)
+            assert torch.equal(envs[0].reward, envs[1].reward) and torch.equal(envs[0].done, envs[1].done)
+            envs[0].reset_done(); envs[1].reset_done()
+        for e in envs:
+            e.close()
+
+
+def test_queue_refill_continues_the_instance_streams():
+    """queue_depth = 1 with refill_slot between episodes: episode k of environment i plays the k-th instance of its
+    reference stream (native generator), exactly like k successive reset() calls of the reference env."""
+    from oracle import oracle as orc
+    cfg = named_config("c3")
+    B = 8
+    env = BatchedPlacementEnv(cfg, B, queue_depth=1, run_seed=7)
+    first = env.generate_instances()[0]
+    streams = [InstanceStream(cfg, env_seed(7, i)) for i in range(B)]
+    want0 = pack_instances(cfg, [s.next() for s in streams])
+    assert np.array_equal(first, want0)
+    env.reset()
+    ob = orc.OracleBatch(cfg, B)
+    ob.reset_packed(want0)
+    for ep in range(3):
+        for t in range(cfg.max_num_components):
+            a = env.sample_actions(ep * 100 + t)
+            _, r, d, _ = env.step(a)
+            rr, dd, _ = ob.step(a.cpu().numpy())
+            assert np.array_equal(r.cpu().numpy().view(np.uint64), rr.view(np.uint64)) and np.array_equal(d.cpu().numpy(), dd)
+        assert bool(env.done.all())
+        nxt = env.refill_slot(0)
+        want = pack_instances(cfg, [s.next() for s in streams])
+        assert np.array_equal(nxt, want), ep
+        env.reset_done()
+        ob.reset_packed(want)
+        got = env.obs["all_components_feature"].cpu().numpy()
+        for i in range(B):
+            assert np.array_equal(got[i], ob.env(i).obs()["all_components_feature"])
+    env.close()

@@ -193,6 +193,11 @@ void pcbenv_instgen_destroy(pcbenv_instgen *gen);
 int pcbenv_instgen_next(pcbenv_instgen *gen, void *record_out);
 int pcbenv_instgen_next_batch(pcbenv_instgen *const *streams, int32_t n, void *records_out, int32_t threads);
 
+/* Smallest and largest number of resets any environment has performed so far (= queue cursors; the next reset of
+ * an environment with cursor c reads slot c % queue_depth).  A slot whose episode index is below *min_out has been
+ * consumed by every environment and may be refilled.  Synchronises with `stream`. */
+int pcbenv_queue_cursors(pcbenv *env, uint32_t *min_out, uint32_t *max_out, void *stream);
+
 /* Checkpoint / resume of the library-owned environment state (all state blocks, pcbenv_state_bytes() bytes of
  * host memory; the instance queue is an input and is reloaded by the caller).  Synchronous w.r.t. `stream`. */
 int64_t pcbenv_state_bytes(const pcbenv *env);

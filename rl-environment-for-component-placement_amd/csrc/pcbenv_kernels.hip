@@ -1119,6 +1119,23 @@ __global__ __launch_bounds__(64 * NW) void k_step(DevParams p, int *__restrict__
     store_state(smem, p, e, lane);
 }
 
+// min / max of the per-environment queue cursors (one small workgroup; B <= a few thousand headers)
+__global__ __launch_bounds__(256) void k_cursor_range(DevParams p, unsigned *out) {
+    unsigned lo = 0xFFFFFFFFu, hi = 0u;
+    for (int e = threadIdx.x; e < p.B; e += 256) {
+        const unsigned c = ((const EnvHdr *)(p.state + (size_t)e * p.stateStride))->qcursor;
+        lo = min(lo, c); hi = max(hi, c);
+    }
+    for (int o = 32; o > 0; o >>= 1) { lo = min(lo, (unsigned)__shfl_xor((int)lo, o)); hi = max(hi, (unsigned)__shfl_xor((int)hi, o)); }
+    __shared__ unsigned slo[4], shi[4];
+    if ((threadIdx.x & 63) == 0) { slo[threadIdx.x >> 6] = lo; shi[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++) { lo = min(lo, slo[w]); hi = max(hi, shi[w]); }
+        out[0] = lo; out[1] = hi;
+    }
+}
+
 // ==============================================================================================
 // host side: the C ABI (include/pcbenv.h)
 // ==============================================================================================
@@ -1128,6 +1145,7 @@ struct pcbenv {
     DevParams dp;
     bool bound;
     int threads;  // workgroup size (threads per environment)
+    unsigned *scratch;  // 16 bytes of device memory for small read-backs
     unsigned loaded_slots;  // bit s = slot s loaded for all environments at least once
     char err[256];
 };
@@ -1310,6 +1328,7 @@ extern "C" void pcbenv_destroy(pcbenv *env) {
     DeviceGuard guard_(env->device);
     if (env->dp.state) hipFree(env->dp.state);
     if (env->dp.queue) hipFree(env->dp.queue);
+    if (env->scratch) hipFree(env->scratch);
     delete env;
 }
 
@@ -1501,5 +1520,17 @@ extern "C" int pcbenv_rollout_sampled(pcbenv *env, int32_t *actions_out_dev, int
     for (int t = 0; t < num_steps; t++)
         dispatch_step(env, actions_out_dev + per_step * (size_t)t, fmt, 1, seed, first_env_index, step_index0 + (uint64_t)t, (hipStream_t)stream);
     HIP_TRY(env, hipGetLastError());
+    return PCBENV_OK;
+}
+
+extern "C" int pcbenv_queue_cursors(pcbenv *env, uint32_t *min_out, uint32_t *max_out, void *stream) {
+    if (!env || !min_out || !max_out) return fail(env, PCBENV_EINVAL, "null argument");
+    DEVICE_GUARD(env);
+    if (!env->scratch) HIP_TRY(env, hipMalloc((void **)&env->scratch, 16));
+    hipLaunchKernelGGL(k_cursor_range, dim3(1), dim3(256), 0, (hipStream_t)stream, env->dp, env->scratch);
+    unsigned host[2] = {0, 0};
+    HIP_TRY(env, hipMemcpyAsync(host, env->scratch, 8, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(env, hipStreamSynchronize((hipStream_t)stream));
+    *min_out = host[0]; *max_out = host[1];
     return PCBENV_OK;
 }

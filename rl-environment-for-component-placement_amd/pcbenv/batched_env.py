@@ -248,6 +248,12 @@ class BatchedPlacementEnv:
             int(step_index0), self._stream()), self._h)
         return out
 
+    def queue_cursors(self):
+        """(min, max) over the environments of the number of resets performed so far (synchronises)."""
+        lo, hi = C.c_uint32(), C.c_uint32()
+        _lib.check(self._L.pcbenv_queue_cursors(self._h, C.byref(lo), C.byref(hi), self._stream()), self._h)
+        return lo.value, hi.value
+
     # -- checkpoint / resume ------------------------------------------------------------------
     def state_dict(self) -> dict:
         """Library state + observation tensors (host copies).  The reference never serialises env state

@@ -437,3 +437,33 @@ def test_queue_refill_continues_the_instance_streams():
         for i in range(B):
             assert np.array_equal(got[i], ob.env(i).obs()["all_components_feature"])
     env.close()
+
+
+def test_instance_feeder_keeps_streams_in_order():
+    """Background generation + stream-ordered refills: over 7 episodes with a 2-deep queue every environment plays
+    instance k of its reference stream in episode k (checked through the oracle on the same streams)."""
+    from oracle import oracle as orc
+    from pcbenv.feeder import InstanceFeeder
+    cfg = named_config("c3")
+    B, Q = 16, 2
+    env = BatchedPlacementEnv(cfg, B, queue_depth=Q, run_seed=8, auto_reset=True)
+    env.generate_instances()
+    env.reset()
+    assert env.queue_cursors() == (1, 1)
+    streams = [InstanceStream(cfg, env_seed(8, i)) for i in range(B)]
+    ob = orc.OracleBatch(cfg, B)
+    ob.reset_packed(pack_instances(cfg, [s.next() for s in streams]))
+    with InstanceFeeder(env, prefetch=3) as feeder:
+        for ep in range(7):
+            for t in range(cfg.max_num_components):
+                _, r, d, _, a = env.rollout_step(ep * 64 + t)
+                rr, dd, _ = ob.step(a.cpu().numpy())
+                assert np.array_equal(r.cpu().numpy().view(np.uint64), rr.view(np.uint64)) and np.array_equal(d.cpu().numpy(), dd)
+            assert bool(env.done.all())
+            ob.reset_packed(pack_instances(cfg, [s.next() for s in streams]))   # what the reference would draw next
+            got = env.obs["all_components_feature"].cpu().numpy()
+            for i in range(B):
+                assert np.array_equal(got[i], ob.env(i).obs()["all_components_feature"]), (ep, i)
+            feeder.refill(block=True)
+    assert env.queue_cursors() == (8, 8)
+    env.close()

@@ -97,7 +97,7 @@ typedef struct pcbenv_config {
     int32_t num_envs;          /* environments on this device (one handle per process / GPU) */
     int32_t queue_depth;       /* instances queued per environment (>= 1) */
     uint32_t flags;
-    int32_t reserved;          /* 0 = choose; 64 / 256 = threads (1 / 4 wavefronts) per environment */
+    int32_t threads_per_env;   /* 0 = choose; 64 / 256 = threads (1 / 4 wavefronts) per environment */
 } pcbenv_config;
 
 /* Observation tensors (device pointers, C-contiguous, leading dim num_envs).

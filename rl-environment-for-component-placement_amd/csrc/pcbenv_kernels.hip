@@ -1306,7 +1306,7 @@ extern "C" int pcbenv_create(const pcbenv_config *cfg, int device, pcbenv **out)
         d.ldsBytes = align16(d.ldsCls + (cls > seg ? cls : seg));
     }
     // threads per environment: one wave up to 64x64 cells of output per plane, four waves above
-    env->threads = c.reserved == 64 || c.reserved == 256 ? c.reserved
+    env->threads = c.threads_per_env == 64 || c.threads_per_env == 256 ? c.threads_per_env
                    : ((long long)c.height * c.width * (c.kind == PCBENV_SPATIAL ? d.K + 5 : 5) > 64 * 1024 ? 256 : 64);
     DeviceGuard guard_(device);
     if (!guard_.ok) { int r = fail(0, PCBENV_EHIP, "hipSetDevice failed (no such device?)"); delete env; return r; }

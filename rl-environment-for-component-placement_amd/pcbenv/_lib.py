@@ -28,7 +28,7 @@ class PcbenvConfig(C.Structure):
         "min_num_nets", "max_num_nets", "max_num_pins_per_net", "min_num_pins_per_net", "reward_type",
         "reward_beam_width", "component_n")] + [
         ("weight_wirelength", C.c_double), ("weight_num_intersections", C.c_double),
-        ("num_envs", C.c_int32), ("queue_depth", C.c_int32), ("flags", C.c_uint32), ("reserved", C.c_int32)]
+        ("num_envs", C.c_int32), ("queue_depth", C.c_int32), ("flags", C.c_uint32), ("threads_per_env", C.c_int32)]
 
 
 BUFFER_FIELDS = ("grid", "action_mask", "pin_grid", "component_grid", "all_components_feature",
@@ -91,7 +91,7 @@ def make_config(cfg, num_envs: int, queue_depth: int = 1, flags: int = 0) -> Pcb
     for name, _ in PcbenvConfig._fields_:
         if name == "reward_type":
             c.reward_type = cfg.reward_type_code
-        elif name in ("num_envs", "queue_depth", "flags", "reserved"):
+        elif name in ("num_envs", "queue_depth", "flags", "threads_per_env"):
             continue
         else:
             setattr(c, name, getattr(cfg, name))

@@ -72,7 +72,7 @@ class BatchedPlacementEnv:
         self._ccfg = _lib.make_config(cfg, num_envs, queue_depth,
                                       (_lib.FLAG_INCREMENTAL_OBS if incremental_obs else 0)
                                       | (_lib.FLAG_AUTO_RESET if auto_reset else 0))
-        self._ccfg.reserved = int(threads_per_env)  # 0 = auto; 64 / 128 / 256 threads (1 / 2 / 4 waves) per environment
+        self._ccfg.threads_per_env = int(threads_per_env)  # 0 = auto; 64 / 256 threads (1 / 4 waves) per environment
         h = C.c_void_p()
         dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         _lib.check(self._L.pcbenv_create(C.byref(self._ccfg), dev_index, C.byref(h)))

@@ -259,7 +259,7 @@ def main():
                    "cpu_model": host_cpu_model(), "host_logical_cpus": os.cpu_count()}
         line = {"metric": "env_steps_per_sec", "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5),
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u64 bit-rows + f64 reward",
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
                 "data": "synthetic (reference-exact instance generator, seeds 1000003*run_seed+env; uniform legal actions drawn on device)",
                 "config": {"workload": f"{args.config}: {cfg.height}x{cfg.width} grid, {cfg.max_num_components} components, "
                                        f"{cfg.max_total_pins} pins, reward={args.reward}", "envs_per_gpu": B,

@@ -1,7 +1,9 @@
 // pcbenv_kernels.hip -- CDNA4 (gfx950) kernels + C ABI of libpcbenv.so.
 //
-// One environment per workgroup, one wavefront (64 lanes) per workgroup.
-// The occupancy grid lives bit-packed (one row = WW 64-bit words) in a compact
+// One environment per workgroup: one wavefront (64 lanes) up to 64x64 cells, four wavefronts for the 128x128
+// spatial configuration (template parameter NW).  Kernels: k_reset, k_step (transition + legal mask +
+// observations + terminal routing reward + optional in-launch reset and action sampling), k_sample,
+// k_cursor_range.  The occupancy grid lives bit-packed (one row = WW 64-bit words) in a compact
 // per-environment state block in HBM that is staged through LDS; the legal
 // placement mask is OR-folds of row words (horizontal: shifts; vertical: LDS
 // neighbours); the observation tensors the policy consumes (uint8 cells) are a
@@ -48,8 +50,8 @@ struct __attribute__((aligned(16))) EnvHdr {
     short ncomp, nnets, npins, cur;  // cur = index of the current component, -1 = sentinel (all placed)
     unsigned episode;                // completed resets
     unsigned qcursor;                // next queue slot
-    unsigned flag;                   // LDS scratch word for workgroup-wide any()
-    unsigned pad[2];                 // (pad[0..2] double as the broadcast slot of the fused sampler)
+    unsigned flag;                   // LDS scratch word: workgroup-wide any(), and y of the sampled action
+    unsigned pad[2];                 // LDS scratch: (o, x) of the action drawn by wavefront 0 (fused sampler)
     unsigned feat_gen;               // bind generation for which the pin-feature tensors hold only this env's rows
 };
 static_assert(sizeof(EnvHdr) == HDR_BYTES, "header size");

@@ -147,6 +147,11 @@ class BatchedPlacementEnv:
         Returns the packed records per slot (uint8 [B, instance_stride])."""
         if self.cfg.kind == KIND_SQUARE:
             return []
+        mode = ("native", bool(verify)) if native else ("numpy", False)
+        if getattr(self, "_gen_mode", mode) != mode:
+            raise RuntimeError("generate_instances: keep the same generator (native / verify) for the lifetime of the "
+                               "environment -- every call continues the per-environment RNG streams")
+        self._gen_mode = mode
         seeds = [env_seed(self.run_seed, self.first_env_index + i) for i in range(self.num_envs)]
         if native and self._native is None:
             from .instances import NativeInstanceStreams

@@ -71,5 +71,30 @@ class SingleEnvAdapter:
     def grid(self) -> np.ndarray:
         return self._env.obs["grid"][0].cpu().numpy().astype(self._dtype)
 
+    @property
+    def components(self):
+        """Read-only view with the reference's attribute names (`Component`: h, w, area, comp_id, placed, position,
+        pins; `Pin`: relative_x/y, absolute_x/y, pin_id, component_id, net_id) built from the instance and the current
+        feature tensors -- what `utils/agent/utils.py:238` reads to save a rollout."""
+        from types import SimpleNamespace
+        if self.instance is None:
+            return []
+        feat = self._env.obs["all_components_feature"][0].cpu().numpy()
+        ins, out = self.instance, []
+        spatial = self.cfg.kind == KIND_SPATIAL
+        pins_num = self._env.obs["all_pins_num_feature"][0].cpu().numpy() if self.cfg.kind in (KIND_PIN, KIND_SPATIAL) else None
+        for c in range(ins.num_components):
+            x, y = int(feat[c, 2]), int(feat[c, 3])
+            pins = []
+            if spatial:  # rows are indexed by the global pin id, so current (rotated) coordinates can be read back
+                for q in np.flatnonzero(ins.pin_comp == c):
+                    r = pins_num[int(ins.pin_id[q])]
+                    pins.append(SimpleNamespace(relative_x=int(r[0]), relative_y=int(r[1]), absolute_x=int(r[2]),
+                                                absolute_y=int(r[3]), pin_id=int(ins.pin_id[q]), component_id=c,
+                                                net_id=int(ins.pin_net[q])))
+            out.append(SimpleNamespace(h=int(ins.comp_h[c]), w=int(ins.comp_w[c]), area=int(ins.comp_h[c] * ins.comp_w[c]),
+                                       comp_id=c, placed=x >= 0, position=(x, y), pins=pins))
+        return out
+
     def close(self):
         self._env.close()

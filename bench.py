@@ -83,6 +83,8 @@ def cpu_baseline(cfg, run_seed, sample_envs, sample_steps, queue_depth):
         _, r, d, _ = env.step(a)
         acts.append(a.cpu().numpy().copy()); dones.append(d.cpu().numpy().copy()); rewards.append(r.cpu().numpy().copy())
         env.reset_done()
+    n_obs = min(32, sample_envs)  # full observations of the first environments after the last step, for the parity check
+    final_obs = {k: v[:n_obs].cpu().numpy().astype(np.float64) for k, v in env.obs.items()}
     env.close()
     ob = orc.OracleBatch(cfg, sample_envs)
     out = {}
@@ -106,6 +108,9 @@ def cpu_baseline(cfg, run_seed, sample_envs, sample_steps, queue_depth):
             ok &= bool(np.array_equal(d, dones[t]) and np.array_equal(r.view(np.uint64), rewards[t].view(np.uint64)))
             do_reset(d)
         dt = time.perf_counter() - t0
+        for i in range(n_obs):  # observations too (the oracle has reset the finished environments like the GPU did)
+            want = ob.env(i).obs()
+            ok &= all(np.array_equal(final_obs[k][i], want[k]) for k in final_obs)
         out[threads] = (sample_envs * sample_steps / dt, ok)
     return out
 
@@ -256,6 +261,7 @@ def main():
             cpu = {"value": round(res[nthr][0], 1), "unit": "env-steps/s", "cores": nthr, "kind": "port",
                    "sample": f"{sample_envs} envs x {sample_steps} steps of the same instances and action stream (oracle/pcbenv_oracle.c, OpenMP)",
                    "single_thread_value": round(res[1][0], 1), "parity_with_gpu": bool(all(v[1] for v in res.values())),
+                   "parity_scope": "reward + done of every sampled env-step, all observation tensors of 32 environments after the last step",
                    "cpu_model": host_cpu_model(), "host_logical_cpus": os.cpu_count()}
         line = {"metric": "env_steps_per_sec", "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5),

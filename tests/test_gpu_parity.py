@@ -320,6 +320,9 @@ def test_ragged_and_maximum_shapes_vs_oracle():
     # a grid completely filled by one component, and 1x1 components
     _oracle_rollout(EnvConfig.rect(4, 4, 4, 4, 4, 4, 2, 2), 4, episodes=2, p_bad=0.0)
     _oracle_rollout(EnvConfig.rect(6, 6, 1, 1, 1, 1, 3, 1), 4, episodes=2, p_bad=0.1)
+    # components as large as the largest grid (128-bit row folds with shifts >= 64)
+    _oracle_rollout(EnvConfig.rect(128, 128, 1, 128, 1, 128, 6, 1), 6, episodes=3, p_bad=0.0)
+    _oracle_rollout(EnvConfig.rect(128, 128, 40, 100, 30, 90, 6, 2), 6, episodes=3, p_bad=0.02, threads=256)
 
 
 @pytest.mark.parametrize("name,B", [("c3", 4096), ("c4", 4096), ("c5", 8192)])

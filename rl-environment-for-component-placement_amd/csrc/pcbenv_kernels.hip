@@ -210,12 +210,12 @@ __device__ inline bool is_intersect(double x1, double y1, double x2, double y2, 
 // ---- routes -------------------------------------------------------------------------------------
 // A route is kept as one segment slot per pin q (slots of net n are nstart[n]..nstart[n+1]-1, so slots are
 // net-major like the reference's route lists); act[q] = 1 if the slot carries a segment.
-struct SegView { double *X1, *Y1, *X2, *Y2, *D, *A, *DX, *DY, *cen; int *act, *nstart, *pre; unsigned short *pairs; unsigned char *beam; };
+struct SegView { double *X1, *Y1, *X2, *Y2, *D, *A, *DX, *DY, *cen; int *act, *nstart, *pre; unsigned *bbox; unsigned short *pairs; unsigned char *beam; };
 #define PAIR_BUF 128  // per-wavefront compaction buffer of candidate (i, j) pairs
 // [segments X1 Y1 X2 Y2 D | centroids | act nstart] then a zone used only by the pair count (A DX DY pre pairs),
 // which the beam search -- finished before the count starts -- overlays with its per-net scratch.
 #define SEG_FIXED_BYTES(P) ((5 * (P) + 2 * PCBENV_MAX_NETS) * 8 + ((P) + PCBENV_MAX_NETS + 4) * 4)
-#define SEG_COUNT_BYTES(P) (3 * (P) * 8 + ((P) + 2) * 4 + 4 * PAIR_BUF * 2)
+#define SEG_COUNT_BYTES(P) (3 * (P) * 8 + (2 * (P) + 2) * 4 + 4 * PAIR_BUF * 2)
 #define SEG_LDS_BYTES(P, beam) (((SEG_FIXED_BYTES(P) + 7) & ~7) + ((beam) > SEG_COUNT_BYTES(P) ? (beam) : SEG_COUNT_BYTES(P)))
 __device__ inline SegView seg_view(double *seg, int P) {
     SegView v;
@@ -226,7 +226,8 @@ __device__ inline SegView seg_view(double *seg, int P) {
     v.beam = (unsigned char *)seg + ((SEG_FIXED_BYTES(P) + 7) & ~7);
     v.A = (double *)v.beam; v.DX = v.A + P; v.DY = v.A + 2 * P;  // per segment: x1*y2 - y1*x2, x1 - x2, y1 - y2
     v.pre = (int *)(v.A + 3 * P);                     // [P + 1] prefix of pair counts
-    v.pairs = (unsigned short *)(v.pre + P + 2);      // [4 wavefronts][PAIR_BUF]
+    v.bbox = (unsigned *)(v.pre + P + 2);             // [P] integer extents (x_lo, x_hi, y_lo, y_hi), one byte each
+    v.pairs = (unsigned short *)(v.bbox + P);         // [4 wavefronts][PAIR_BUF]
     return v;
 }
 
@@ -263,8 +264,6 @@ __device__ inline void build_centroid_segments(const SegView &v, const EnvHdr *h
     lds_sync();
 }
 
-// S:629-651 find_num_intersection + S:704-722 find_wirelength over the slots.  The (segment, later-net segment)
-// pairs are flattened over the 64 lanes; the wirelength is summed sequentially in route order (bit-exact).
 // is_intersect (S:653-702) on two slots, with the per-segment terms hoisted: the operations and their order are
 // exactly the reference's -- (x1*y2 - y1*x2), (x1 - x2), (y1 - y2) are sub-expressions of its formulas.
 __device__ inline bool slots_intersect(const SegView &v, int i, int j) {
@@ -282,12 +281,19 @@ __device__ inline bool slots_intersect(const SegView &v, int i, int j) {
 }
 // Exact pre-filter: if the closed x- (or y-) extents of the two segments are disjoint, no x (y) can lie in both,
 // so the reference's final range test fails whatever the computed intersection point is (a shared end point,
-// its only early "True", puts a common point in both extents).  Saves the two float64 divisions.
-__device__ inline bool extents_overlap(const SegView &v, int i, int j) {
-    const double x1 = v.X1[i], y1 = v.Y1[i], x2 = v.X2[i], y2 = v.Y2[i];
-    const double x3 = v.X1[j], y3 = v.Y1[j], x4 = v.X2[j], y4 = v.Y2[j];
-    return fmax(fmin(x1, x2), fmin(x3, x4)) <= fmin(fmax(x1, x2), fmax(x3, x4)) &&
-           fmax(fmin(y1, y2), fmin(y3, y4)) <= fmin(fmax(y1, y2), fmax(y3, y4));
+// its only early "True", puts a common point in both extents).  The extents are kept as conservatively rounded
+// integers (floor of the minimum, ceil of the maximum; coordinates are in [0, 127]), four bytes per segment, so
+// the filter is one LDS word per segment and a few integer compares; a pair it lets through is decided by the
+// full float64 test, a pair it rejects has disjoint real extents.  Saves the two float64 divisions.
+__device__ inline unsigned pack_extents(double x1, double y1, double x2, double y2) {
+    const unsigned xl = (unsigned)floor(fmin(x1, x2)), xh = (unsigned)ceil(fmax(x1, x2));
+    const unsigned yl = (unsigned)floor(fmin(y1, y2)), yh = (unsigned)ceil(fmax(y1, y2));
+    return xl | (xh << 8) | (yl << 16) | (yh << 24);
+}
+__device__ inline bool extents_overlap(unsigned a, unsigned b) {
+    const unsigned xl = max(a & 0xFFu, b & 0xFFu), xh = min((a >> 8) & 0xFFu, (b >> 8) & 0xFFu);
+    const unsigned yl = max((a >> 16) & 0xFFu, (b >> 16) & 0xFFu), yh = min(a >> 24, b >> 24);
+    return xl <= xh && yl <= yh;
 }
 
 // S:629-651 find_num_intersection + S:704-722 find_wirelength over the slots.  The (segment, later-net segment)
@@ -301,12 +307,23 @@ __device__ inline void count_and_length(const SegView &v, const EnvHdr *hdr, con
     for (int q = lane; q < np; q += NT) {
         const double x1 = v.X1[q], y1 = v.Y1[q], x2 = v.X2[q], y2 = v.Y2[q];
         v.A[q] = x1 * y2 - y1 * x2; v.DX[q] = x1 - x2; v.DY[q] = y1 - y2;
+        v.bbox[q] = v.act[q] ? pack_extents(x1, y1, x2, y2) : 0u;
     }
-    if (lane == 0) {
-        int acc = 0;
-        for (int i = 0; i < np; i++) { v.pre[i] = acc; if (v.act[i]) acc += np - v.nstart[pins[i].net + 1]; }
-        v.pre[np] = acc;
-        *total_cnt = 0;
+    // pre[i] = number of (slot, later-net slot) pairs before slot i: exclusive scan by wavefront 0, four slots per lane
+    if (lane < WAVE) {
+        int c[4], sum = 0;
+        #pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = 4 * lane + k;
+            c[k] = (i < np && v.act[i]) ? np - v.nstart[pins[i].net + 1] : 0;
+            sum += c[k];
+        }
+        int incl = sum;
+        for (int d = 1; d < WAVE; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+        int run = incl - sum;
+        #pragma unroll
+        for (int k = 0; k < 4; k++) { const int i = 4 * lane + k; if (i <= np) v.pre[i] = run; run += c[k]; }
+        if (lane == 0) *total_cnt = 0;
     }
     lds_sync();
     const int total = v.pre[np];
@@ -320,7 +337,7 @@ __device__ inline void count_and_length(const SegView &v, const EnvHdr *hdr, con
         if (t < total) {
             while (v.pre[i + 1] <= t) i++;  // pre[] is non-decreasing and t only grows: amortised O(1)
             j = v.nstart[pins[i].net + 1] + (t - v.pre[i]);
-            pass = v.act[j] && extents_overlap(v, i, j);
+            pass = v.act[j] && extents_overlap(v.bbox[i], v.bbox[j]);
         }
         const u64 ball = __ballot(pass);
         if (pass) buf[nbuf + __popcll(ball & ((1ull << wl_lane) - 1ull))] = (unsigned short)(i | (j << 8));
@@ -337,8 +354,16 @@ __device__ inline void count_and_length(const SegView &v, const EnvHdr *hdr, con
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
     if (wl_lane == 0 && cnt) atomicAdd(total_cnt, cnt);
     lds_sync();
+    // find_wirelength: the adds happen in route order; empty slots add +0.0, which leaves a non-negative sum
+    // unchanged bit for bit, so the loads of a block of eight are independent of the running sum
     double wl = 0.0;
-    for (int q = 0; q < np; q++) if (v.act[q]) wl += v.D[q];
+    for (int q = 0; q < np; q += 8) {
+        double t8[8];
+        #pragma unroll
+        for (int k = 0; k < 8; k++) t8[k] = (q + k < np && v.act[q + k]) ? v.D[q + k] : 0.0;
+        #pragma unroll
+        for (int k = 0; k < 8; k++) wl += t8[k];
+    }
     *wirelength = wl;
     *nintersections = *total_cnt;
     lds_sync();

@@ -288,12 +288,12 @@ __device__ inline bool slots_intersect(const SegView &v, int i, int j) {
 __device__ inline unsigned pack_extents(double x1, double y1, double x2, double y2) {
     const unsigned xl = (unsigned)floor(fmin(x1, x2)), xh = (unsigned)ceil(fmax(x1, x2));
     const unsigned yl = (unsigned)floor(fmin(y1, y2)), yh = (unsigned)ceil(fmax(y1, y2));
-    return xl | (xh << 8) | (yl << 16) | (yh << 24);
+    return xl | (xh << 8) | (yl << 16) | (yh << 24) | 0x80000000u;  // bit 31 = slot carries a segment
 }
 __device__ inline bool extents_overlap(unsigned a, unsigned b) {
     const unsigned xl = max(a & 0xFFu, b & 0xFFu), xh = min((a >> 8) & 0xFFu, (b >> 8) & 0xFFu);
-    const unsigned yl = max((a >> 16) & 0xFFu, (b >> 16) & 0xFFu), yh = min(a >> 24, b >> 24);
-    return xl <= xh && yl <= yh;
+    const unsigned yl = max((a >> 16) & 0xFFu, (b >> 16) & 0xFFu), yh = min((a >> 24) & 0x7Fu, (b >> 24) & 0x7Fu);
+    return (a & b & 0x80000000u) != 0 && xl <= xh && yl <= yh;
 }
 
 // S:629-651 find_num_intersection + S:704-722 find_wirelength over the slots.  The (segment, later-net segment)
@@ -329,15 +329,31 @@ __device__ inline void count_and_length(const SegView &v, const EnvHdr *hdr, con
     const int total = v.pre[np];
     const int wl_lane = lane & 63;
     volatile unsigned short *buf = v.pairs + (lane >> 6) * PAIR_BUF;  // wave-synchronous: written and read by different lanes
-    int cnt = 0, nbuf = 0, i = 0;
-    for (int base = 0; base < total; base += NT) {  // wave-uniform trip count
-        const int t = base + lane;
+    // Every thread walks a contiguous run of the flattened pair index t = pre[i] + (j - first partner of i): the
+    // partner j advances by one per step, so a step is one LDS word (the partner's packed extents) instead of a
+    // search; the slot i and its extents stay in registers and change only when its partners are exhausted.
+    const int chunk = (total + NT - 1) / NT;
+    int t = lane * chunk;
+    const int tend = min(total, t + chunk);
+    int cnt = 0, nbuf = 0, i = 0, j = 0, iend = 0;
+    unsigned bi = 0;
+    if (t < tend) {
+        int lo = 0, hi = np;  // largest i with pre[i] <= t
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (v.pre[mid] <= t) lo = mid; else hi = mid; }
+        i = lo;
+        while (v.pre[i + 1] <= t) i++;  // skip slots without partners that share pre[]
+        bi = v.bbox[i]; iend = v.pre[i + 1];
+        j = v.nstart[pins[i].net + 1] + (t - v.pre[i]);
+    }
+    for (int step = 0; step < chunk; step++) {  // wave-uniform trip count
         bool pass = false;
-        int j = 0;
-        if (t < total) {
-            while (v.pre[i + 1] <= t) i++;  // pre[] is non-decreasing and t only grows: amortised O(1)
-            j = v.nstart[pins[i].net + 1] + (t - v.pre[i]);
-            pass = v.act[j] && extents_overlap(v.bbox[i], v.bbox[j]);
+        if (t < tend) {
+            if (t >= iend) {  // partners of slot i exhausted: next slot that has any
+                do { i++; } while (v.pre[i + 1] <= t);
+                bi = v.bbox[i]; iend = v.pre[i + 1];
+                j = v.nstart[pins[i].net + 1];
+            }
+            pass = extents_overlap(bi, v.bbox[j]);
         }
         const u64 ball = __ballot(pass);
         if (pass) buf[nbuf + __popcll(ball & ((1ull << wl_lane) - 1ull))] = (unsigned short)(i | (j << 8));
@@ -349,6 +365,7 @@ __device__ inline void count_and_length(const SegView &v, const EnvHdr *hdr, con
             nbuf -= WAVE;
             if (wl_lane < nbuf) buf[wl_lane] = keep;
         }
+        t++; j++;
     }
     if (wl_lane < nbuf) { const unsigned short pr = buf[wl_lane]; if (slots_intersect(v, pr & 0xFF, pr >> 8)) cnt++; }
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);

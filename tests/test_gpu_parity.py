@@ -470,3 +470,48 @@ def test_instance_feeder_keeps_streams_in_order():
             feeder.refill(block=True)
     assert env.queue_cursors() == (8, 8)
     env.close()
+
+
+def _mix64(z):
+    M = (1 << 64) - 1
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+    return z ^ (z >> 31)
+
+
+def test_sampler_definition():
+    """The uniform legal-action draw is a documented function of (seed, global env index, step index, mask bits):
+    rnd = mix64(mix64(seed ^ GOLDEN*(env+1)) + step); pick = floor(hi32(rnd) * n / 2^32) over the n = reps*popcount
+    legal actions in (orientation, row, column) order -- checked here against a host computation from mask_bits(),
+    independently of how the kernel scans and selects."""
+    M = (1 << 64) - 1
+    for name, first in (("c1", 0), ("c2", 7), ("c4", 1000), ("c5", 3)):
+        cfg = named_config(name)
+        B = 12
+        env = BatchedPlacementEnv(cfg, B, queue_depth=1, run_seed=5, first_env_index=first)
+        env.generate_instances(); env.reset()
+        H, W = cfg.height, cfg.width
+        nplanes = 1 if cfg.kind == KIND_SQUARE else 2
+        reps = 2 if cfg.kind in (KIND_PIN, KIND_SPATIAL) else 1
+        for t in range(cfg.max_num_components + 2 if cfg.kind != KIND_SQUARE else 6):
+            bits = env.mask_bits().cpu().numpy().view(np.uint64)[:, :nplanes]          # [B, planes, H, WW]
+            a = env.sample_actions(t).cpu().numpy()
+            for e in range(B):
+                words = bits[e].reshape(-1)
+                setbits = [(wi, b) for wi, w in enumerate(words) for b in range(64) if (int(w) >> b) & 1]
+                total = len(setbits)
+                if total == 0:
+                    assert tuple(a[e]) == (0, 0, 0)
+                    continue
+                rnd = _mix64((_mix64((5 ^ ((0x9E3779B97F4A7C15 * (first + e + 1)) & M)) & M) + t) & M)
+                pick = ((rnd >> 32) * (total * reps)) >> 32
+                k, rep = pick % total, pick // total
+                wi, b = setbits[k]
+                WW = (W + 63) // 64
+                plane, rw = divmod(wi, H * WW)
+                x, wcol = divmod(rw, WW)
+                want = (plane + 2 * rep, x, wcol * 64 + b)
+                assert tuple(int(v) for v in a[e]) == want, (name, t, e, tuple(a[e]), want)
+            env.step(torch.from_numpy(a))
+            env.reset_done()
+        env.close()

@@ -837,12 +837,30 @@ __device__ inline u64 mix64(u64 z) {  // splitmix64 finaliser
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return z ^ (z >> 31);
 }
-__device__ inline int select_bit(u64 w, int k) {  // position of the k-th (0-based) set bit
-    for (int i = 0; i < k; i++) w &= w - 1;
-    return __ffsll((long long)w) - 1;
+__device__ inline int select_bit(u64 w, int k) {  // position of the k-th (0-based) set bit: binary search on popcounts
+    int pos = 0;
+    #pragma unroll
+    for (int width = 32; width >= 1; width >>= 1) {
+        const int c = __popcll(w & ((1ull << width) - 1ull));
+        if (k >= c) { k -= c; w >>= width; pos += width; }
+    }
+    return pos;
+}
+// Inclusive prefix sum over the 64 lanes with DPP row shifts / row broadcasts (no LDS round trips).
+__device__ inline int wave_inclusive_scan(int x, int lane) {
+    const int row = lane & 15;
+    int t;
+    t = __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false); if (row >= 1) x += t;   // row_shr:1
+    t = __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false); if (row >= 2) x += t;   // row_shr:2
+    t = __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false); if (row >= 4) x += t;   // row_shr:4
+    t = __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false); if (row >= 8) x += t;   // row_shr:8
+    t = __builtin_amdgcn_update_dpp(0, x, 0x142, 0xF, 0xF, false); if ((lane & 31) >= 16) x += t;  // row_bcast:15
+    t = __builtin_amdgcn_update_dpp(0, x, 0x143, 0xF, 0xF, false); if (lane >= 32) x += t;         // row_bcast:31
+    return x;
 }
 // Uniform draw over the set bits of the legal-action bit mask vm (planes 0/1; pin kinds also mirror them as
-// orientations 2/3): per-lane popcounts, wave prefix sum, owner lane selects the k-th set bit.
+// orientations 2/3): per-lane popcounts of a contiguous run of words, wave prefix sum, the owner lane selects
+// the k-th set bit.  rnd = mix64(mix64(seed ^ GOLDEN*(env+1)) + step); pick = hi32(rnd) * n >> 32.
 __device__ inline void sample_action(const u64 *vm, const DevParams &p, int genv, int lane, u64 seed, u64 step_index,
                                      int *o, int *x, int *y) {
     const int WW = p.WW, plane = p.H * WW;
@@ -850,31 +868,33 @@ __device__ inline void sample_action(const u64 *vm, const DevParams &p, int genv
     const int per = (words + WAVE - 1) / WAVE;
     int mine = 0;
     for (int i = lane * per; i < (lane + 1) * per && i < words; i++) mine += __popcll(vm[i]);
-    int incl = mine;
-    for (int d = 1; d < WAVE; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
-    const int total = __shfl(incl, WAVE - 1);
+    const int incl = wave_inclusive_scan(mine, lane);
+    const int total = __builtin_amdgcn_readlane(incl, WAVE - 1);
     *o = 0; *x = 0; *y = 0;
     if (total <= 0) return;
     const u64 rnd = mix64(mix64(seed ^ 0x9E3779B97F4A7C15ull * ((u64)genv + 1)) + step_index);
-    const int reps = (p.kind == PCBENV_PIN || p.kind == PCBENV_SPATIAL) ? 2 : 1;
-    const unsigned pick = (unsigned)(((rnd >> 32) * (u64)(total * reps)) >> 32);
-    const int k = (int)(pick % (unsigned)total), rep = (int)(pick / (unsigned)total);
+    const bool mirrored = (p.kind == PCBENV_PIN || p.kind == PCBENV_SPATIAL);  // two orientations per mask plane
+    const unsigned pick = (unsigned)(((rnd >> 32) * (u64)(mirrored ? 2 * total : total)) >> 32);
+    const int rep = pick >= (unsigned)total ? 1 : 0, k = (int)pick - rep * total;
     const int excl = incl - mine;
     const bool owner = k >= excl && k < incl;
-    int found = -1;
+    int found = 0;
     if (owner) {
         int rem = k - excl;
         for (int i = lane * per; i < (lane + 1) * per && i < words; i++) {
-            const int c = __popcll(vm[i]);
-            if (rem < c) { found = i * 64 + select_bit(vm[i], rem); break; }
+            const u64 w = vm[i];
+            const int c = __popcll(w);
+            if (rem < c) { found = i * 64 + select_bit(w, rem); break; }
             rem -= c;
         }
     }
     const u64 ball = __ballot(owner);
-    found = __shfl(found, __ffsll((long long)ball) - 1);
+    found = __builtin_amdgcn_readlane(found, __builtin_amdgcn_readfirstlane(__ffsll((long long)ball) - 1));
     const int word = found >> 6, bit = found & 63;
-    const int pl = word / plane, rw = word - pl * plane;
-    *o = pl + 2 * rep; *x = rw / WW; *y = (rw - *x * WW) * 64 + bit;
+    const int pl = word >= plane ? 1 : 0, rw = word - pl * plane;
+    *o = pl + 2 * rep;
+    *x = WW == 1 ? rw : rw >> 1;
+    *y = (rw - *x * WW) * 64 + bit;
 }
 __global__ __launch_bounds__(WAVE) void k_sample(DevParams p, int *__restrict__ actions, int fmt, u64 seed,
                                                  u64 first_env, u64 step_index) {

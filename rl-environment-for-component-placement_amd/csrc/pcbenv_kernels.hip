@@ -345,18 +345,21 @@ __device__ inline void count_and_length(const SegView &v, const EnvHdr *hdr, con
         bi = v.bbox[i]; iend = v.pre[i + 1];
         j = v.nstart[pins[i].net + 1] + (t - v.pre[i]);
     }
+    unsigned bj = t < tend ? v.bbox[j] : 0u;
     for (int step = 0; step < chunk; step++) {  // wave-uniform trip count
-        bool pass = false;
-        if (t < tend) {
+        const bool pass = t < tend && extents_overlap(bi, bj);
+        const unsigned short code = (unsigned short)(i | (j << 8));
+        t++; j++;
+        if (t < tend) {  // fetch the next partner's extents now: the LDS latency hides behind the compaction below
             if (t >= iend) {  // partners of slot i exhausted: next slot that has any
                 do { i++; } while (v.pre[i + 1] <= t);
                 bi = v.bbox[i]; iend = v.pre[i + 1];
                 j = v.nstart[pins[i].net + 1];
             }
-            pass = extents_overlap(bi, v.bbox[j]);
+            bj = v.bbox[j];
         }
         const u64 ball = __ballot(pass);
-        if (pass) buf[nbuf + __popcll(ball & ((1ull << wl_lane) - 1ull))] = (unsigned short)(i | (j << 8));
+        if (pass) buf[nbuf + __popcll(ball & ((1ull << wl_lane) - 1ull))] = code;
         nbuf += __popcll(ball);
         if (nbuf >= WAVE) {  // a dense batch of 64 candidates
             const unsigned short pr = buf[wl_lane];
@@ -365,21 +368,28 @@ __device__ inline void count_and_length(const SegView &v, const EnvHdr *hdr, con
             nbuf -= WAVE;
             if (wl_lane < nbuf) buf[wl_lane] = keep;
         }
-        t++; j++;
     }
     if (wl_lane < nbuf) { const unsigned short pr = buf[wl_lane]; if (slots_intersect(v, pr & 0xFF, pr >> 8)) cnt++; }
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
     if (wl_lane == 0 && cnt) atomicAdd(total_cnt, cnt);
     lds_sync();
     // find_wirelength: the adds happen in route order; empty slots add +0.0, which leaves a non-negative sum
-    // unchanged bit for bit, so the loads of a block of eight are independent of the running sum
+    // unchanged bit for bit.  Every lane fetches the lengths of its own slots once (one LDS round trip), the sum
+    // then runs over v_readlane broadcasts.
+    double dreg[4];
+    #pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int sidx = 64 * r + wl_lane;
+        dreg[r] = (sidx < np && v.act[sidx]) ? v.D[sidx] : 0.0;
+    }
     double wl = 0.0;
-    for (int q = 0; q < np; q += 8) {
-        double t8[8];
-        #pragma unroll
-        for (int k = 0; k < 8; k++) t8[k] = (q + k < np && v.act[q + k]) ? v.D[q + k] : 0.0;
-        #pragma unroll
-        for (int k = 0; k < 8; k++) wl += t8[k];
+    #pragma unroll
+    for (int ri = 0; ri < 4; ri++) {
+        if (64 * ri >= np) break;
+        const int lim = min(64, np - 64 * ri);
+        const int dlo = __double2loint(dreg[ri]), dhi = __double2hiint(dreg[ri]);
+        for (int il = 0; il < lim; il++)
+            wl += __hiloint2double(__builtin_amdgcn_readlane(dhi, il), __builtin_amdgcn_readlane(dlo, il));
     }
     *wirelength = wl;
     *nintersections = *total_cnt;
@@ -941,17 +951,19 @@ template <int KIND, int WW> __device__ inline void reset_env(const DevParams &p,
         const unsigned char *rec = p.queue + ((size_t)slot * p.B + e) * p.instStride;
         const int *ih = (const int *)rec;
         const int nc = ih[0], nn = ih[1], np = ih[2];
-        const unsigned char *crec = rec + 16, *prec = rec + 16 + 8 * (size_t)p.C;
+        const u64 *crec = (const u64 *)(rec + 16), *prec = crec + p.C;  // 8-byte records, one load each
         for (int c = lane; c < p.C; c += NT) {
-            CompRec cr; cr.h = crec[8 * c]; cr.w = crec[8 * c + 1]; cr.px = -1; cr.py = -1;
+            const u64 w = crec[c];
+            CompRec cr; cr.h = (unsigned char)w; cr.w = (unsigned char)(w >> 8); cr.px = -1; cr.py = -1;
             cr.pad[0] = cr.pad[1] = cr.pad[2] = cr.pad[3] = 0;
             if (c >= nc) { cr.h = 0; cr.w = 0; }
             l.comps[c] = cr;
         }
         for (int q = lane; q < p.P; q += NT) {
-            PinRec pr; pr.rel_x = prec[8 * q]; pr.rel_y = prec[8 * q + 1]; pr.abs_x = -1; pr.abs_y = -1;
-            pr.net = prec[8 * q + 2]; pr.comp = prec[8 * q + 3];
-            pr.id = (unsigned short)(prec[8 * q + 4] | (prec[8 * q + 5] << 8));
+            const u64 w = prec[q];
+            PinRec pr; pr.rel_x = (unsigned char)w; pr.rel_y = (unsigned char)(w >> 8); pr.abs_x = -1; pr.abs_y = -1;
+            pr.net = (unsigned char)(w >> 16); pr.comp = (unsigned char)(w >> 24);
+            pr.id = (unsigned short)(w >> 32);
             if (q >= np) { pr.rel_x = pr.rel_y = 0; pr.net = 0xFF; pr.comp = 0xFF; pr.id = 0; }
             l.pins[q] = pr;
         }
@@ -960,13 +972,31 @@ template <int KIND, int WW> __device__ inline void reset_env(const DevParams &p,
             l.hdr->qcursor += 1; l.hdr->episode += 1;
         }
         lds_sync();
-        if (KIND == PCBENV_PIN) {  // quirk Q1: rows [component, pin_id] collide; the last writer in self.pins order wins
-            for (int q = lane; q < np; q += NT) {
-                bool loser = false;
-                for (int r = q + 1; r < np; r++)
-                    loser |= (l.pins[r].comp == l.pins[q].comp && (l.pins[r].id & PIN_ID_MASK) == (l.pins[q].id & PIN_ID_MASK));
-                if (loser) l.pins[q].id |= PIN_LOSER;
+        if (KIND == PCBENV_PIN && lane < WAVE) {
+            // quirk Q1: rows [component, pin_id] collide; the last writer in self.pins order wins.  Wavefront 0 keeps
+            // the (component, pin_id) keys of its lanes' slots in registers and walks the pins with v_readlane:
+            // a slot loses when a later slot carries the same key.
+            unsigned key[4]; bool lose[4];
+            #pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int sidx = 64 * r + lane;
+                key[r] = sidx < np ? ((unsigned)l.pins[sidx].comp << 16) | (l.pins[sidx].id & PIN_ID_MASK) : 0xFFFFFFFFu;
+                lose[r] = false;
             }
+            #pragma unroll
+            for (int ri = 0; ri < 4; ri++) {
+                if (64 * ri >= np) break;
+                const int lim = min(64, np - 64 * ri);
+                for (int il = 0; il < lim; il++) {
+                    const unsigned ki = (unsigned)__builtin_amdgcn_readlane((int)key[ri], il);
+                    const int i = 64 * ri + il;
+                    #pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        if (64 * r < np && 64 * r + lane < i && key[r] == ki) lose[r] = true;
+                }
+            }
+            #pragma unroll
+            for (int r = 0; r < 4; r++) if (lose[r]) l.pins[64 * r + lane].id |= PIN_LOSER;
         }
     } else if (lane == 0) {
         l.hdr->ncomp = 0; l.hdr->nnets = 0; l.hdr->npins = 0; l.hdr->cur = 0; l.hdr->episode += 1;

@@ -68,6 +68,22 @@ def measured_copy_ceiling_gbps(device):
     return best
 
 
+def measured_fill_ceiling_gbps(device):
+    """Write-only stream (1 GiB `fill_`), best of 5: the path is ~95 % stores, so this is the closer ceiling."""
+    n = 1 << 30
+    a = torch.empty(n, dtype=torch.uint8, device=device)
+    best = 0.0
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        a.fill_(1)
+        e1.record()
+        torch.cuda.synchronize()
+        best = max(best, n / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    del a
+    return best
+
+
 def cpu_baseline(cfg, run_seed, sample_envs, sample_steps, queue_depth):
     """Time the CPU oracle (port of the reference) on a bounded sample; parity-check it against the GPU."""
     from oracle import oracle as orc
@@ -251,6 +267,7 @@ def main():
             roof = {"bound": "hbm", "kernel": "k_step", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                     "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                     "measured_copy_ceiling": round(measured_copy_ceiling_gbps(env.device), 1),
+                    "measured_fill_ceiling": round(measured_fill_ceiling_gbps(env.device), 1),
                     "algorithmic_bytes_per_env_step": b_alg, "units_per_launch": B,
                     "kernel_ms": round(step_kernel_ms, 5)}
         cpu = None

@@ -19,6 +19,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "pcbenv.h"
@@ -28,7 +29,7 @@ typedef unsigned long long u64;
 #define WAVE 64
 #define NT ((int)blockDim.x)   // threads per environment: 64 (one wave) or 256 (four waves, large grids)
 #define MAX_NT 256
-#define HDR_BYTES 32
+#define HDR_BYTES 64
 
 // ----------------------------------------------------------------------------------------------
 // device-side parameter block (kernel argument, by value)
@@ -43,7 +44,17 @@ struct DevParams {
     int ldsHf, ldsCls, ldsSeg, ldsBytes;    // byte offsets of LDS scratch behind the state mirror
     unsigned char *state, *queue;
     pcbenv_buffers buf;
+    unsigned long long *dbg;                // diagnostic build only (-DPCBENV_STAMPS): [B][32] s_memtime stamps
 };
+// In-kernel stamps (cdna_hip_programming.md §7): only in a separate diagnostic build, written to a buffer nothing
+// else reads; `PCBENV_STAMPS=1` in the environment allocates it, tools/kernel_stamps.py prints the phase profile.
+#ifdef PCBENV_STAMPS
+#define STAMP(k) do { if (threadIdx.x == 0 && p.dbg) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); p.dbg[(size_t)blockIdx.x * 32 + (k)] = t_; } } while (0)
+#define STAMP_RT(k) do { if (threadIdx.x == 0 && p.dbg) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); p.dbg[(size_t)blockIdx.x * 32 + (k)] = t_; } } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#define STAMP_RT(k) do { } while (0)
+#endif
 
 // per-environment header at the start of a state block
 struct __attribute__((aligned(16))) EnvHdr {
@@ -53,6 +64,14 @@ struct __attribute__((aligned(16))) EnvHdr {
     unsigned flag;                   // LDS scratch word: workgroup-wide any(), and y of the sampled action
     unsigned pad[2];                 // LDS scratch: (o, x) of the action drawn by wavefront 0 (fused sampler)
     unsigned feat_gen;               // bind generation for which the pin-feature tensors hold only this env's rows
+    // Action of the NEXT fused-sampler step, drawn at the end of the launch that produced the mask (while its
+    // stores drain) instead of at the head of the next launch, where the whole grid would wait for it.  Valid
+    // (bit 31 of pre_action) only for exactly this (seed, step index, global env index) and only while vm is the
+    // mask it was drawn from: every launch that rewrites vm redraws or clears it.
+    u64 pre_seed, pre_step;
+    unsigned pre_action;             // o | x << 8 | y << 16 | 1 << 31
+    unsigned pre_genv;
+    unsigned rsv[2];
 };
 static_assert(sizeof(EnvHdr) == HDR_BYTES, "header size");
 
@@ -127,12 +146,25 @@ template <int WW> __device__ inline Row<WW> hfold(Row<WW> r, int pw) {
     return f;
 }
 
-// 16-byte observation store.  -DPCBENV_NT_STORES: non-temporal (streaming) variant, kept for A/B measurements.
-#ifdef PCBENV_NT_STORES
+// 16-byte observation / state store, agent-scope write-through (`sc1`): every line written here is next read by
+// another launch (usually on another XCD) or by the policy, never by this workgroup, so leaving it dirty in the
+// XCD's L2 only defers the write to the end-of-kernel release, where the whole grid waits for it (+5 % at c3).
+// -DPCBENV_STORE_PLAIN / -DPCBENV_NT_STORES / -DPCBENV_STORE_ASM="..." keep the alternatives for A/B runs.
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
+#define PCB_STR_(x) #x
+#define PCB_STR(x) PCB_STR_(x)
+#if defined(PCBENV_STORE_PLAIN)
+__device__ inline void STORE16(uint4 *p, uint4 v) { *p = v; }
+#elif defined(PCBENV_NT_STORES)
 __device__ inline void STORE16(uint4 *p, uint4 v) { __builtin_nontemporal_store(v4u{v.x, v.y, v.z, v.w}, (v4u *)p); }
 #else
-__device__ inline void STORE16(uint4 *p, uint4 v) { *p = v; }
+#ifndef PCBENV_STORE_ASM
+#define PCBENV_STORE_ASM sc1
+#endif
+__device__ inline void STORE16(uint4 *p, uint4 v) {
+    v4u w{v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off " PCB_STR(PCBENV_STORE_ASM) :: "v"(p), "v"(w) : "memory");
+}
 #endif
 
 // 4 mask bits -> 4 bytes of 0/1
@@ -189,6 +221,19 @@ __device__ inline bool window_mask(const u64 *occ, u64 *hf, u64 *vm, int H, int 
     return block_any(any, flag);
 }
 
+// Inclusive prefix sum over the 64 lanes with DPP row shifts / row broadcasts (no LDS round trips).
+__device__ inline int wave_inclusive_scan(int x, int lane) {
+    const int row = lane & 15;
+    int t;
+    t = __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false); if (row >= 1) x += t;   // row_shr:1
+    t = __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false); if (row >= 2) x += t;   // row_shr:2
+    t = __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false); if (row >= 4) x += t;   // row_shr:4
+    t = __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false); if (row >= 8) x += t;   // row_shr:8
+    t = __builtin_amdgcn_update_dpp(0, x, 0x142, 0xF, 0xF, false); if ((lane & 31) >= 16) x += t;  // row_bcast:15
+    t = __builtin_amdgcn_update_dpp(0, x, 0x143, 0xF, 0xF, false); if (lane >= 32) x += t;         // row_bcast:31
+    return x;
+}
+
 // ----------------------------------------------------------------------------------------------
 // float64 geometry of the reward (one IEEE operation per operator, see file header)
 // ----------------------------------------------------------------------------------------------
@@ -210,13 +255,14 @@ __device__ inline bool is_intersect(double x1, double y1, double x2, double y2, 
 // ---- routes -------------------------------------------------------------------------------------
 // A route is kept as one segment slot per pin q (slots of net n are nstart[n]..nstart[n+1]-1, so slots are
 // net-major like the reference's route lists); act[q] = 1 if the slot carries a segment.
-struct SegView { double *X1, *Y1, *X2, *Y2, *D, *A, *DX, *DY, *cen; int *act, *nstart, *pre; unsigned *bbox; unsigned short *pairs; unsigned char *beam; };
-#define PAIR_BUF 128  // per-wavefront compaction buffer of candidate (i, j) pairs
-// [segments X1 Y1 X2 Y2 D | centroids | act nstart] then a zone used only by the pair count (A DX DY pre pairs),
+struct SegView { double *X1, *Y1, *X2, *Y2, *D, *A, *DX, *DY, *cen; int *act, *nstart; unsigned *bbox; unsigned short *ns, *pairs; unsigned char *beam; };
+// compaction buffer of candidate (i, j) pairs: 1024 entries for a one-wavefront workgroup, 512 per wavefront for four
+#define PAIR_ENTRIES(NW) ((NW) == 1 ? 1024 : 2048)
+// [segments X1 Y1 X2 Y2 D | centroids | act nstart] then a zone used only by the pair count (A DX DY bbox ns pairs),
 // which the beam search -- finished before the count starts -- overlays with its per-net scratch.
 #define SEG_FIXED_BYTES(P) ((5 * (P) + 2 * PCBENV_MAX_NETS) * 8 + ((P) + PCBENV_MAX_NETS + 4) * 4)
-#define SEG_COUNT_BYTES(P) (3 * (P) * 8 + (2 * (P) + 2) * 4 + 4 * PAIR_BUF * 2)
-#define SEG_LDS_BYTES(P, beam) (((SEG_FIXED_BYTES(P) + 7) & ~7) + ((beam) > SEG_COUNT_BYTES(P) ? (beam) : SEG_COUNT_BYTES(P)))
+#define SEG_COUNT_BYTES(P, NW) (3 * (P) * 8 + (P) * 4 + (((P) + 1) & ~1) * 2 + PAIR_ENTRIES(NW) * 2)
+#define SEG_LDS_BYTES(P, NW, beam) (((SEG_FIXED_BYTES(P) + 7) & ~7) + ((beam) > SEG_COUNT_BYTES(P, NW) ? (beam) : SEG_COUNT_BYTES(P, NW)))
 __device__ inline SegView seg_view(double *seg, int P) {
     SegView v;
     v.X1 = seg; v.Y1 = seg + P; v.X2 = seg + 2 * P; v.Y2 = seg + 3 * P; v.D = seg + 4 * P;
@@ -225,9 +271,9 @@ __device__ inline SegView seg_view(double *seg, int P) {
     v.nstart = v.act + P;                             // [nnets + 1] (+ spare counter slot)
     v.beam = (unsigned char *)seg + ((SEG_FIXED_BYTES(P) + 7) & ~7);
     v.A = (double *)v.beam; v.DX = v.A + P; v.DY = v.A + 2 * P;  // per segment: x1*y2 - y1*x2, x1 - x2, y1 - y2
-    v.pre = (int *)(v.A + 3 * P);                     // [P + 1] prefix of pair counts
-    v.bbox = (unsigned *)(v.pre + P + 2);             // [P] integer extents (x_lo, x_hi, y_lo, y_hi), one byte each
-    v.pairs = (unsigned short *)(v.bbox + P);         // [4 wavefronts][PAIR_BUF]
+    v.bbox = (unsigned *)(v.A + 3 * P);               // [P] integer extents (x_lo, x_hi, y_lo, y_hi), one byte each
+    v.ns = (unsigned short *)(v.bbox + P);            // [P] first slot of the slot's own net (= number of earlier-net slots)
+    v.pairs = v.ns + ((P + 1) & ~1);                  // [PAIR_ENTRIES] shared out among the wavefronts
     return v;
 }
 
@@ -266,18 +312,21 @@ __device__ inline void build_centroid_segments(const SegView &v, const EnvHdr *h
 
 // is_intersect (S:653-702) on two slots, with the per-segment terms hoisted: the operations and their order are
 // exactly the reference's -- (x1*y2 - y1*x2), (x1 - x2), (y1 - y2) are sub-expressions of its formulas.
+// Written without branches so that several candidates per lane can be in flight at once (the count is bound by
+// the LDS and float64 division latency of one wavefront, not by issue slots): det == 0 gives inf / NaN
+// coordinates, which is harmless and masked by the explicit test.
 __device__ inline bool slots_intersect(const SegView &v, int i, int j) {
     const double x1 = v.X1[i], y1 = v.Y1[i], x2 = v.X2[i], y2 = v.Y2[i];
     const double x3 = v.X1[j], y3 = v.Y1[j], x4 = v.X2[j], y4 = v.Y2[j];
-    if ((x1 == x3 && y1 == y3) || (x1 == x4 && y1 == y4) || (x2 == x3 && y2 == y3) || (x2 == x4 && y2 == y4)) return true;
     const double dxi = v.DX[i], dyi = v.DY[i], dxj = v.DX[j], dyj = v.DY[j];
-    const double det = dxi * dyj - dyi * dxj;
-    if (det == 0) return false;
     const double a = v.A[i], b = v.A[j];
+    const bool shared = ((x1 == x3) & (y1 == y3)) | ((x1 == x4) & (y1 == y4)) | ((x2 == x3) & (y2 == y3)) | ((x2 == x4) & (y2 == y4));
+    const double det = dxi * dyj - dyi * dxj;
     const double x = (a * dxj - dxi * b) / det;
     const double y = (a * dyj - dyi * b) / det;
-    return fmin(x1, x2) <= x && x <= fmax(x1, x2) && fmin(x3, x4) <= x && x <= fmax(x3, x4) &&
-           fmin(y1, y2) <= y && y <= fmax(y1, y2) && fmin(y3, y4) <= y && y <= fmax(y3, y4);
+    const bool inside = (fmin(x1, x2) <= x) & (x <= fmax(x1, x2)) & (fmin(x3, x4) <= x) & (x <= fmax(x3, x4)) &
+                        (fmin(y1, y2) <= y) & (y <= fmax(y1, y2)) & (fmin(y3, y4) <= y) & (y <= fmax(y3, y4));
+    return shared | ((det != 0) & inside);
 }
 // Exact pre-filter: if the closed x- (or y-) extents of the two segments are disjoint, no x (y) can lie in both,
 // so the reference's final range test fails whatever the computed intersection point is (a shared end point,
@@ -290,118 +339,126 @@ __device__ inline unsigned pack_extents(double x1, double y1, double x2, double 
     const unsigned yl = (unsigned)floor(fmin(y1, y2)), yh = (unsigned)ceil(fmax(y1, y2));
     return xl | (xh << 8) | (yl << 16) | (yh << 24) | 0x80000000u;  // bit 31 = slot carries a segment
 }
-__device__ inline bool extents_overlap(unsigned a, unsigned b) {
+__device__ inline bool extents_overlap(unsigned a, unsigned b) {  // branch-free
     const unsigned xl = max(a & 0xFFu, b & 0xFFu), xh = min((a >> 8) & 0xFFu, (b >> 8) & 0xFFu);
     const unsigned yl = max((a >> 16) & 0xFFu, (b >> 16) & 0xFFu), yh = min((a >> 24) & 0x7Fu, (b >> 24) & 0x7Fu);
-    return (a & b & 0x80000000u) != 0 && xl <= xh && yl <= yh;
+    return ((a & b & 0x80000000u) != 0) & (xl <= xh) & (yl <= yh);
+}
+
+// Full test on the n candidates a wavefront has collected, two per lane and step so that their LDS reads and
+// divisions overlap.
+typedef __attribute__((address_space(3))) unsigned short lds_u16;  // keeps the buffer accesses ds_* instead of flat_*
+__device__ inline int count_candidates(const SegView &v, const volatile lds_u16 *buf, int n, int wl_lane) {
+    int cnt = 0;
+    for (int base = 0; base < n; base += 2 * WAVE) {
+        const int i0 = base + wl_lane, i1 = i0 + WAVE;
+        const unsigned short p0 = i0 < n ? buf[i0] : (unsigned short)0, p1 = i1 < n ? buf[i1] : (unsigned short)0;
+        const bool r0 = slots_intersect(v, p0 & 0xFF, p0 >> 8), r1 = slots_intersect(v, p1 & 0xFF, p1 >> 8);
+        cnt += ((i0 < n) & r0) + ((i1 < n) & r1);
+    }
+    return cnt;
 }
 
 // S:629-651 find_num_intersection + S:704-722 find_wirelength over the slots.  The (segment, later-net segment)
-// pairs are flattened over the lanes; each wavefront first filters its pairs by extent overlap, compacts the
-// survivors into an LDS buffer (ballot + prefix) and runs the full test on dense batches of 64.  The wirelength
+// pairs are first filtered by extent overlap, the survivors compacted into an LDS buffer and run through the full
+// test in dense batches (see count_finish).  The wirelength
 // is summed sequentially in route order (bit-exact with the reference's python float loop).
-__device__ inline void count_and_length(const SegView &v, const EnvHdr *hdr, const PinRec *pins, int lane,
-                                        double *wirelength, int *nintersections) {
-    const int np = hdr->npins;
+// count_prepare reads the pins, count_finish only the segment zone.
+__device__ inline void count_prepare(const SegView &v, int np, const PinRec *pins, int lane) {
     int *total_cnt = v.nstart + PCBENV_MAX_NETS + 1;  // spare slot behind nstart[0..MAX_NETS]
     for (int q = lane; q < np; q += NT) {
         const double x1 = v.X1[q], y1 = v.Y1[q], x2 = v.X2[q], y2 = v.Y2[q];
         v.A[q] = x1 * y2 - y1 * x2; v.DX[q] = x1 - x2; v.DY[q] = y1 - y2;
         v.bbox[q] = v.act[q] ? pack_extents(x1, y1, x2, y2) : 0u;
+        v.ns[q] = (unsigned short)v.nstart[pins[q].net];
     }
-    // pre[i] = number of (slot, later-net slot) pairs before slot i: exclusive scan by wavefront 0, four slots per lane
-    if (lane < WAVE) {
-        int c[4], sum = 0;
-        #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int i = 4 * lane + k;
-            c[k] = (i < np && v.act[i]) ? np - v.nstart[pins[i].net + 1] : 0;
-            sum += c[k];
-        }
-        int incl = sum;
-        for (int d = 1; d < WAVE; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
-        int run = incl - sum;
-        #pragma unroll
-        for (int k = 0; k < 4; k++) { const int i = 4 * lane + k; if (i <= np) v.pre[i] = run; run += c[k]; }
-        if (lane == 0) *total_cnt = 0;
-    }
+    if (lane == 0) *total_cnt = 0;
     lds_sync();
-    const int total = v.pre[np];
-    const int wl_lane = lane & 63;
-    volatile unsigned short *buf = v.pairs + (lane >> 6) * PAIR_BUF;  // wave-synchronous: written and read by different lanes
-    // Every thread walks a contiguous run of the flattened pair index t = pre[i] + (j - first partner of i): the
-    // partner j advances by one per step, so a step is one LDS word (the partner's packed extents) instead of a
-    // search; the slot i and its extents stay in registers and change only when its partners are exhausted.
-    const int chunk = (total + NT - 1) / NT;
-    int t = lane * chunk;
-    const int tend = min(total, t + chunk);
-    int cnt = 0, nbuf = 0, i = 0, j = 0, iend = 0;
-    unsigned bi = 0;
-    if (t < tend) {
-        int lo = 0, hi = np;  // largest i with pre[i] <= t
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (v.pre[mid] <= t) lo = mid; else hi = mid; }
-        i = lo;
-        while (v.pre[i + 1] <= t) i++;  // skip slots without partners that share pre[]
-        bi = v.bbox[i]; iend = v.pre[i + 1];
-        j = v.nstart[pins[i].net + 1] + (t - v.pre[i]);
-    }
-    unsigned bj = t < tend ? v.bbox[j] : 0u;
-    for (int step = 0; step < chunk; step++) {  // wave-uniform trip count
-        const bool pass = t < tend && extents_overlap(bi, bj);
-        const unsigned short code = (unsigned short)(i | (j << 8));
-        t++; j++;
-        if (t < tend) {  // fetch the next partner's extents now: the LDS latency hides behind the compaction below
-            if (t >= iend) {  // partners of slot i exhausted: next slot that has any
-                do { i++; } while (v.pre[i + 1] <= t);
-                bi = v.bbox[i]; iend = v.pre[i + 1];
-                j = v.nstart[pins[i].net + 1];
+}
+__device__ inline void count_finish(const DevParams &p, const SegView &v, int np_, int lane, double *wirelength, int *nintersections) {
+    int *total_cnt = v.nstart + PCBENV_MAX_NETS + 1;
+    const int np = __builtin_amdgcn_readfirstlane(np_);
+    STAMP(12);
+    const int wl_lane = lane & 63, wave = lane >> 6, nwaves = NT / WAVE;
+    const int cap = PAIR_ENTRIES(nwaves) / nwaves;
+    volatile lds_u16 *buf = (volatile lds_u16 *)(v.pairs + wave * cap);  // wave-synchronous: written and read by different lanes
+    // Slots are net-major, so the partners "segment of an earlier net" of slot j are the slots i < ns[j].  The work
+    // is cut into 64 x 64 tiles (j chunk, i chunk <= j chunk) dealt out to the wavefronts.  In a tile lane j keeps
+    // its packed extents in a register and the wavefront sweeps the i chunk: one broadcast LDS word per step, no
+    // dependent reads; the survivors of a step are appended to the compaction buffer with a ballot.  That leaves the
+    // buffer i-major with ascending j, so a dense batch reads the i side as broadcasts and the j side from
+    // consecutive addresses.  The buffer is run through the full test whenever another step might not fit.
+    const int nchunk = (np + WAVE - 1) / WAVE, ntiles = nchunk * (nchunk + 1) / 2;
+    int cnt = 0, nbuf = 0;
+    for (int tile = wave; tile < ntiles; tile += nwaves) {  // wave-uniform
+        int jc = 0, ic = tile;
+        while (ic > jc) { ic -= jc + 1; jc++; }
+        const int j = WAVE * jc + wl_lane;
+        const unsigned bj = j < np ? v.bbox[j] : 0u;
+        const int lim = j < np ? (int)v.ns[j] : 0;
+        // ns grows with j, so the last slot of the chunk bounds the sweep; readfirstlane keeps the trip count in an SGPR
+        const int i0 = WAVE * ic;
+        const int i1 = __builtin_amdgcn_readfirstlane(min(i0 + WAVE, (int)v.ns[min(np - 1, WAVE * jc + WAVE - 1)]));
+        for (int ib = i0; ib < i1; ib += 4) {
+            unsigned bi[4];
+            #pragma unroll
+            for (int u = 0; u < 4; u++) bi[u] = v.bbox[min(ib + u, i1 - 1)];  // the four reads go out together
+            #pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = ib + u;
+                const bool pass = (i < i1) & (i < lim) & extents_overlap(bi[u], bj);
+                const u64 ball = __ballot(pass);
+                if (pass) buf[nbuf + __popcll(ball & ((1ull << wl_lane) - 1ull))] = (unsigned short)(i | (j << 8));
+                nbuf += __popcll(ball);
             }
-            bj = v.bbox[j];
-        }
-        const u64 ball = __ballot(pass);
-        if (pass) buf[nbuf + __popcll(ball & ((1ull << wl_lane) - 1ull))] = code;
-        nbuf += __popcll(ball);
-        if (nbuf >= WAVE) {  // a dense batch of 64 candidates
-            const unsigned short pr = buf[wl_lane];
-            const unsigned short keep = buf[WAVE + wl_lane];
-            if (slots_intersect(v, pr & 0xFF, pr >> 8)) cnt++;
-            nbuf -= WAVE;
-            if (wl_lane < nbuf) buf[wl_lane] = keep;
+            if (nbuf > cap - 4 * WAVE) { cnt += count_candidates(v, buf, nbuf, wl_lane); nbuf = 0; }  // no room for another group
         }
     }
-    if (wl_lane < nbuf) { const unsigned short pr = buf[wl_lane]; if (slots_intersect(v, pr & 0xFF, pr >> 8)) cnt++; }
+    STAMP(13);
+    cnt += count_candidates(v, buf, nbuf, wl_lane);
+    STAMP(14);
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
     if (wl_lane == 0 && cnt) atomicAdd(total_cnt, cnt);
     lds_sync();
+    STAMP(15);
     // find_wirelength: the adds happen in route order; empty slots add +0.0, which leaves a non-negative sum
     // unchanged bit for bit.  Every lane fetches the lengths of its own slots once (one LDS round trip), the sum
     // then runs over v_readlane broadcasts.
-    double dreg[4];
-    #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const int sidx = 64 * r + wl_lane;
-        dreg[r] = (sidx < np && v.act[sidx]) ? v.D[sidx] : 0.0;
-    }
     double wl = 0.0;
-    #pragma unroll
-    for (int ri = 0; ri < 4; ri++) {
-        if (64 * ri >= np) break;
-        const int lim = min(64, np - 64 * ri);
-        const int dlo = __double2loint(dreg[ri]), dhi = __double2hiint(dreg[ri]);
-        for (int il = 0; il < lim; il++)
-            wl += __hiloint2double(__builtin_amdgcn_readlane(dhi, il), __builtin_amdgcn_readlane(dlo, il));
+    for (int base = 0; base < np; base += WAVE) {
+        const int sidx = base + wl_lane;
+        const double d = (sidx < np && v.act[sidx]) ? v.D[sidx] : 0.0;
+        const int dlo = __double2loint(d), dhi = __double2hiint(d);
+        #pragma unroll
+        for (int blk = 0; blk < WAVE; blk += 16) {  // constant lane selects: the broadcasts run ahead of the add chain
+            if (base + blk >= np) break;
+            #pragma unroll
+            for (int il = blk; il < blk + 16; il++)
+                wl += __hiloint2double(__builtin_amdgcn_readlane(dhi, il), __builtin_amdgcn_readlane(dlo, il));
+        }
     }
     *wirelength = wl;
     *nintersections = *total_cnt;
     lds_sync();
+}
+__device__ inline void count_and_length(const DevParams &p, const SegView &v, const EnvHdr *hdr, const PinRec *pins, int lane,
+                                        double *wirelength, int *nintersections) {
+    const int np = hdr->npins;
+    count_prepare(v, np, pins, lane);
+    count_finish(p, v, np, lane, wirelength, nintersections);
 }
 
 __device__ inline void route_centroid(const DevParams &p, const EnvHdr *hdr, const PinRec *pins, double *seg,
                                       int lane, double *wirelength, int *nintersections) {
     const SegView v = seg_view(seg, p.P);
     net_offsets_and_centroids(v, hdr, pins, lane);
+    STAMP(5);
     build_centroid_segments(v, hdr, pins, lane);
-    count_and_length(v, hdr, pins, lane, wirelength, nintersections);
+    STAMP(6);
+    count_prepare(v, hdr->npins, pins, lane);
+    STAMP(22);
+    count_finish(p, v, hdr->npins, lane, wirelength, nintersections);
+    STAMP(8);
 }
 
 // ---- beam-search routing (S:1273-1286 pin_outlier, S:1303-1369 beam_search, S:1371-1406) -----------------
@@ -661,11 +718,11 @@ __device__ inline void route_beam_or_both(const DevParams &p, const EnvHdr *hdr,
     for (int n = lane; n < hdr->nnets; n += NT)
         beam_route_net(v, pins, v.nstart[n], v.nstart[n + 1] - v.nstart[n], p.beam_width, beam + (size_t)n * BEAM_LDS_PER_NET(p.beam_width));
     lds_sync();
-    count_and_length(v, hdr, pins, lane, wirelength, nintersections);
+    count_and_length(p, v, hdr, pins, lane, wirelength, nintersections);
     if (p.reward_type == PCBENV_REWARD_BOTH) {  // S:609-627 lowest_num_intersections: ties keep the beam route
         double wc; int kc;
         build_centroid_segments(v, hdr, pins, lane);
-        count_and_length(v, hdr, pins, lane, &wc, &kc);
+        count_and_length(p, v, hdr, pins, lane, &wc, &kc);
         if (kc < *nintersections) { *nintersections = kc; *wirelength = wc; }
     }
 }
@@ -699,6 +756,7 @@ __device__ inline void store_state(const unsigned char *smem, const DevParams &p
     lds_sync();
     uint4 *dst = (uint4 *)(p.state + (size_t)e * p.stateStride);
     const uint4 *src = (const uint4 *)smem;
+    // plain write-back stores: environment e runs on XCD e % 8 in every launch, so its state block is an L2 hit next step
     for (int i = lane; i < (int)(p.stateStride / 16); i += NT) dst[i] = src[i];
 }
 
@@ -856,18 +914,6 @@ __device__ inline int select_bit(u64 w, int k) {  // position of the k-th (0-bas
     }
     return pos;
 }
-// Inclusive prefix sum over the 64 lanes with DPP row shifts / row broadcasts (no LDS round trips).
-__device__ inline int wave_inclusive_scan(int x, int lane) {
-    const int row = lane & 15;
-    int t;
-    t = __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false); if (row >= 1) x += t;   // row_shr:1
-    t = __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false); if (row >= 2) x += t;   // row_shr:2
-    t = __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false); if (row >= 4) x += t;   // row_shr:4
-    t = __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false); if (row >= 8) x += t;   // row_shr:8
-    t = __builtin_amdgcn_update_dpp(0, x, 0x142, 0xF, 0xF, false); if ((lane & 31) >= 16) x += t;  // row_bcast:15
-    t = __builtin_amdgcn_update_dpp(0, x, 0x143, 0xF, 0xF, false); if (lane >= 32) x += t;         // row_bcast:31
-    return x;
-}
 // Uniform draw over the set bits of the legal-action bit mask vm (planes 0/1; pin kinds also mirror them as
 // orientations 2/3): per-lane popcounts of a contiguous run of words, wave prefix sum, the owner lane selects
 // the k-th set bit.  rnd = mix64(mix64(seed ^ GOLDEN*(env+1)) + step); pick = hi32(rnd) * n >> 32.
@@ -922,6 +968,19 @@ __global__ __launch_bounds__(WAVE) void k_sample(DevParams p, int *__restrict__ 
 // reset (R:310-351, P:1544-1597, S:1487-1549, Q:74-113): header is in LDS; builds the new episode's state in
 // LDS from the next queued instance and rewrites every observation tensor of environment e.
 // ----------------------------------------------------------------------------------------------
+// The next queued instance of environment e: header and 8-byte records, all loads issued together.
+struct InstRegs { int nc, nn, np; u64 comp; u64 pin[4]; };
+__device__ inline void fetch_instance(const DevParams &p, unsigned qcursor, int e, int lane, InstRegs &ir) {
+    const unsigned slot = qcursor % (unsigned)p.Q;
+    const unsigned char *rec = p.queue + ((size_t)slot * p.B + e) * p.instStride;
+    const int *ih = (const int *)rec;
+    const u64 *crec = (const u64 *)(rec + 16), *prec = crec + p.C;  // 8-byte records, one load each
+    ir.nc = ih[0]; ir.nn = ih[1]; ir.np = ih[2];
+    ir.comp = lane < p.C ? crec[lane] : 0ull;
+    #pragma unroll
+    for (int r = 0; r < 4; r++) { const int q = lane + r * NT; ir.pin[r] = q < p.P ? prec[q] : 0ull; }
+}
+
 template <int KIND, int WW> __device__ inline void reset_env(const DevParams &p, Lds &l, int e, int lane) {
     const int H = p.H, W = p.W, HW = H * W;
     lds_sync();
@@ -947,20 +1006,21 @@ template <int KIND, int WW> __device__ inline void reset_env(const DevParams &p,
     lds_sync();
     for (int i = lane; i < H * WW; i += NT) l.occ[i] = 0ull;
     if (KIND != PCBENV_SQUARE) {
-        const unsigned slot = l.hdr->qcursor % (unsigned)p.Q;
-        const unsigned char *rec = p.queue + ((size_t)slot * p.B + e) * p.instStride;
-        const int *ih = (const int *)rec;
-        const int nc = ih[0], nn = ih[1], np = ih[2];
-        const u64 *crec = (const u64 *)(rec + 16), *prec = crec + p.C;  // 8-byte records, one load each
-        for (int c = lane; c < p.C; c += NT) {
-            const u64 w = crec[c];
+        InstRegs ir;
+        fetch_instance(p, l.hdr->qcursor, e, lane, ir);
+        const int nc = ir.nc, nn = ir.nn, np = ir.np;
+        if (lane < p.C) {
+            const u64 w = ir.comp;
             CompRec cr; cr.h = (unsigned char)w; cr.w = (unsigned char)(w >> 8); cr.px = -1; cr.py = -1;
             cr.pad[0] = cr.pad[1] = cr.pad[2] = cr.pad[3] = 0;
-            if (c >= nc) { cr.h = 0; cr.w = 0; }
-            l.comps[c] = cr;
+            if (lane >= nc) { cr.h = 0; cr.w = 0; }
+            l.comps[lane] = cr;
         }
-        for (int q = lane; q < p.P; q += NT) {
-            const u64 w = prec[q];
+        #pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int q = lane + r * NT;
+            if (q >= p.P) break;
+            const u64 w = ir.pin[r];
             PinRec pr; pr.rel_x = (unsigned char)w; pr.rel_y = (unsigned char)(w >> 8); pr.abs_x = -1; pr.abs_y = -1;
             pr.net = (unsigned char)(w >> 16); pr.comp = (unsigned char)(w >> 24);
             pr.id = (unsigned short)(w >> 32);
@@ -976,33 +1036,48 @@ template <int KIND, int WW> __device__ inline void reset_env(const DevParams &p,
             // quirk Q1: rows [component, pin_id] collide; the last writer in self.pins order wins.  Wavefront 0 keeps
             // the (component, pin_id) keys of its lanes' slots in registers and walks the pins with v_readlane:
             // a slot loses when a later slot carries the same key.
-            unsigned key[4]; bool lose[4];
-            #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int sidx = 64 * r + lane;
-                key[r] = sidx < np ? ((unsigned)l.pins[sidx].comp << 16) | (l.pins[sidx].id & PIN_ID_MASK) : 0xFFFFFFFFu;
-                lose[r] = false;
-            }
-            #pragma unroll
-            for (int ri = 0; ri < 4; ri++) {
-                if (64 * ri >= np) break;
-                const int lim = min(64, np - 64 * ri);
-                for (int il = 0; il < lim; il++) {
-                    const unsigned ki = (unsigned)__builtin_amdgcn_readlane((int)key[ri], il);
-                    const int i = 64 * ri + il;
-                    #pragma unroll
-                    for (int r = 0; r < 4; r++)
-                        if (64 * r < np && 64 * r + lane < i && key[r] == ki) lose[r] = true;
+            if (np <= WAVE) {  // one slot per lane: one ballot per distinct key, its highest lane is the last writer
+                const unsigned key = lane < np ? ((unsigned)l.pins[lane].comp << 16) | (l.pins[lane].id & PIN_ID_MASK) : 0xFFFFFFFFu;
+                u64 remaining = __ballot(lane < np);
+                bool lose = false;
+                while (remaining) {
+                    const unsigned k = (unsigned)__builtin_amdgcn_readlane((int)key, __ffsll((long long)remaining) - 1);
+                    const u64 m = __ballot(key == k);
+                    if (key == k && lane != 63 - __clzll((long long)m)) lose = true;
+                    remaining &= ~m;
                 }
+                if (lose) l.pins[lane].id |= PIN_LOSER;
+            } else {
+                unsigned key[4]; bool lose[4];
+                #pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int sidx = 64 * r + lane;
+                    key[r] = sidx < np ? ((unsigned)l.pins[sidx].comp << 16) | (l.pins[sidx].id & PIN_ID_MASK) : 0xFFFFFFFFu;
+                    lose[r] = false;
+                }
+                #pragma unroll
+                for (int ri = 0; ri < 4; ri++) {
+                    if (64 * ri >= np) break;
+                    const int lim = min(64, np - 64 * ri);
+                    for (int il = 0; il < lim; il++) {
+                        const unsigned ki = (unsigned)__builtin_amdgcn_readlane((int)key[ri], il);
+                        const int i = 64 * ri + il;
+                        #pragma unroll
+                        for (int r = 0; r < 4; r++)
+                            if (64 * r < np && 64 * r + lane < i && key[r] == ki) lose[r] = true;
+                    }
+                }
+                #pragma unroll
+                for (int r = 0; r < 4; r++) if (lose[r]) l.pins[64 * r + lane].id |= PIN_LOSER;
             }
-            #pragma unroll
-            for (int r = 0; r < 4; r++) if (lose[r]) l.pins[64 * r + lane].id |= PIN_LOSER;
         }
     } else if (lane == 0) {
         l.hdr->ncomp = 0; l.hdr->nnets = 0; l.hdr->npins = 0; l.hdr->cur = 0; l.hdr->episode += 1;
     }
     lds_sync();
+    STAMP(16);
     mask_and_emit<KIND, WW>(p, l, e, lane, true, 0, H);
+    STAMP(17);
 
     if (KIND != PCBENV_SQUARE) {
         const int nc = l.hdr->ncomp, np = l.hdr->npins;
@@ -1028,6 +1103,7 @@ template <int KIND, int WW> __device__ inline void reset_env(const DevParams &p,
                 }
             }
         }
+        STAMP(18);
         if (p.buf.placement_mask) {
             double *pm = p.buf.placement_mask + (size_t)e * p.C;
             for (int c = lane; c < p.C; c += NT)
@@ -1063,6 +1139,7 @@ template <int KIND, int WW> __device__ inline void reset_env(const DevParams &p,
                 }
             }
         }
+        STAMP(19);
         if (KIND == PCBENV_SPATIAL) {
             if (p.buf.pin_grid) emit_zero(p.buf.pin_grid + (size_t)e * HW * p.K, (long long)HW * p.K, lane);  // S:1504
             if (p.buf.component_grid) {  // S:1677-1697 draw_components (unrotated rel coords; channel 0 == 1)
@@ -1093,6 +1170,7 @@ __global__ __launch_bounds__(64 * NW) void k_reset(DevParams p, const unsigned c
     Lds l = carve(smem, p);
     reset_env<KIND, WW>(p, l, e, lane);
     if (lane == 0) {
+        l.hdr->pre_action = 0u;  // the mask changed under any presampled action
         p.buf.reward[e] = 0.0;
         p.buf.done[e] = 0;
         if (p.buf.info) { p.buf.info[2 * e] = nan(""); p.buf.info[2 * e + 1] = nan(""); }
@@ -1105,28 +1183,55 @@ __global__ __launch_bounds__(64 * NW) void k_reset(DevParams p, const unsigned c
 //   sampled != 0: the action is drawn here (same generator as k_sample) and written to `actions`
 //   PCBENV_FLAG_AUTO_RESET: a terminal transition is followed, in the same launch, by the reset
 // ----------------------------------------------------------------------------------------------
+// Draw the next fused-sampler action from the mask now in l.vm (see EnvHdr::pre_action), or clear a stale one.
+__device__ inline void presample_next(const DevParams &p, Lds &l, int sampled, int genv, u64 seed, u64 next_step, int lane) {
+    if (lane >= WAVE) return;
+#ifdef PCBENV_NO_PRESAMPLE
+    sampled = 0;
+#endif
+    if (!sampled) { if (lane == 0) l.hdr->pre_action = 0u; return; }
+    int o, x, y;
+    sample_action(l.vm, p, genv, lane, seed, next_step, &o, &x, &y);
+    if (lane == 0) {
+        l.hdr->pre_seed = seed; l.hdr->pre_step = next_step; l.hdr->pre_genv = (unsigned)genv;
+        l.hdr->pre_action = (unsigned)o | ((unsigned)x << 8) | ((unsigned)y << 16) | 0x80000000u;
+    }
+}
+
 template <int KIND, int WW, int NW, bool ROUTES>
 __global__ __launch_bounds__(64 * NW) void k_step(DevParams p, int *__restrict__ actions, int fmt, int sampled,
                                                u64 seed, u64 first_env, u64 step_index) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int e = blockIdx.x, lane = threadIdx.x;
     const int H = p.H, W = p.W, HW = H * W, plane = H * WW;
+    STAMP_RT(30);
+    STAMP(0);
     load_state(smem, p, e, lane);
     Lds l = carve(smem, p);
     const bool auto_reset = p.flags & PCBENV_FLAG_AUTO_RESET;
+    STAMP(1);
 
     int o, x, y;
+    const int genv = (int)first_env + e;
     if (sampled) {
-        if (lane < WAVE) {  // wave 0 draws, the others take the result from LDS
-            sample_action(l.vm, p, (int)first_env + e, lane, seed, step_index, &o, &x, &y);
-            if (lane == 0) {
-                l.hdr->pad[0] = (unsigned)o; l.hdr->pad[1] = (unsigned)x; l.hdr->flag = (unsigned)y;
-                if (fmt == PCBENV_ACTION_FLAT) actions[e] = o * HW + x * W + y;
-                else { actions[3 * e] = o; actions[3 * e + 1] = x; actions[3 * e + 2] = y; }
+        const unsigned pa = l.hdr->pre_action;
+        if ((pa >> 31) && l.hdr->pre_seed == seed && l.hdr->pre_step == step_index && l.hdr->pre_genv == (unsigned)genv) {
+            o = (int)(pa & 0xFFu); x = (int)((pa >> 8) & 0xFFu); y = (int)((pa >> 16) & 0xFFu);  // drawn by the previous launch
+            STAMP(21);
+        } else {
+            if (lane < WAVE) {  // wavefront 0 draws (the result is wave-uniform), the others take it from LDS
+                sample_action(l.vm, p, genv, lane, seed, step_index, &o, &x, &y);
+                if (NW > 1 && lane == 0) { l.hdr->pad[0] = (unsigned)o; l.hdr->pad[1] = (unsigned)x; l.hdr->flag = (unsigned)y; }
+            }
+            if (NW > 1) {
+                lds_sync();
+                o = (int)l.hdr->pad[0]; x = (int)l.hdr->pad[1]; y = (int)l.hdr->flag;
             }
         }
-        lds_sync();
-        o = (int)l.hdr->pad[0]; x = (int)l.hdr->pad[1]; y = (int)l.hdr->flag;
+        if (lane == 0) {
+            if (fmt == PCBENV_ACTION_FLAT) actions[e] = o * HW + x * W + y;
+            else { actions[3 * e] = o; actions[3 * e + 1] = x; actions[3 * e + 2] = y; }
+        }
     } else if (fmt == PCBENV_ACTION_FLAT) {  // utils/environment/env_wrappers.py:80-98, :184-199
         const int a = actions[e];
         if (a < 0 || a >= p.O * HW) { o = -1; x = y = 0; }
@@ -1135,6 +1240,7 @@ __global__ __launch_bounds__(64 * NW) void k_step(DevParams p, int *__restrict__
         o = actions[3 * e]; x = actions[3 * e + 1]; y = actions[3 * e + 2];
         if (KIND == PCBENV_SQUARE) o = 0;
     }
+    STAMP(2);
     const int cur = l.hdr->cur;
     // validate_action (S:1699-1723): action_mask[o, x, y] == 1; anything out of range is invalid
     bool valid = o >= 0 && o < p.O && x >= 0 && x < H && y >= 0 && y < W && (KIND == PCBENV_SQUARE || cur >= 0);
@@ -1147,7 +1253,11 @@ __global__ __launch_bounds__(64 * NW) void k_step(DevParams p, int *__restrict__
         if (lane == 0) p.buf.done[e] = 1;
         if (KIND == PCBENV_SQUARE || KIND == PCBENV_RECT) { if (lane == 0) p.buf.reward[e] = 0.0; }
         else terminal_reward<KIND, ROUTES>(p, l, e, lane);
-        if (auto_reset) { reset_env<KIND, WW>(p, l, e, lane); store_state(smem, p, e, lane); }
+        if (auto_reset) {
+            reset_env<KIND, WW>(p, l, e, lane);
+            presample_next(p, l, sampled, genv, seed, step_index + 1, lane);
+            store_state(smem, p, e, lane);
+        }
         return;
     }
 
@@ -1196,6 +1306,7 @@ __global__ __launch_bounds__(64 * NW) void k_step(DevParams p, int *__restrict__
         }
     }
     lds_sync();
+    STAMP(3);
     // When the last component has just been placed and the reset follows in this launch, the terminal cell
     // tensors would be overwritten at once: skip them (terminal by "no legal cell left" is rare and only
     // costs a double write).
@@ -1204,13 +1315,20 @@ __global__ __launch_bounds__(64 * NW) void k_step(DevParams p, int *__restrict__
     const bool skip_emit = auto_reset && KIND != PCBENV_SQUARE && l.hdr->cur < 0;
     const bool any = mask_and_emit<KIND, WW>(p, l, e, lane, !skip_emit, r0, r1);
     if (KIND == PCBENV_SPATIAL && !skip_emit) emit_pin_grid<WW>(p, l, e, lane, r0, r1);
+    STAMP(4);
     const bool done = KIND == PCBENV_SQUARE ? !any : (l.hdr->cur < 0 || !any);  // S:1856-1869
     if (lane == 0) p.buf.done[e] = done ? 1 : 0;
     if (KIND == PCBENV_SQUARE || KIND == PCBENV_RECT) { if (lane == 0) p.buf.reward[e] = 1.0; }
     else if (!done) { if (lane == 0) p.buf.reward[e] = 0.0; }
     else terminal_reward<KIND, ROUTES>(p, l, e, lane);
+    STAMP(9);
     if (done && auto_reset) reset_env<KIND, WW>(p, l, e, lane);  // rewrites every observation
+    STAMP(10);
+    presample_next(p, l, sampled, genv, seed, step_index + 1, lane);
+    STAMP(20);
     store_state(smem, p, e, lane);
+    STAMP(11);
+    STAMP_RT(31);
 }
 
 // min / max of the per-environment queue cursors (one small workgroup; B <= a few thousand headers)
@@ -1382,6 +1500,9 @@ extern "C" int pcbenv_create(const pcbenv_config *cfg, int device, pcbenv **out)
         double b = mean2(c.min_num_pins_per_net, c.max_num_pins_per_net) * mean2(c.min_num_nets, c.max_num_nets);
         d.int_norm = a < b ? a : b;
     }
+    // threads per environment: one wave up to 64x64 cells of output per plane, four waves above
+    env->threads = c.threads_per_env == 64 || c.threads_per_env == 256 ? c.threads_per_env
+                   : ((long long)c.height * c.width * (c.kind == PCBENV_SPATIAL ? d.K + 5 : 5) > 64 * 1024 ? 256 : 64);
     // state block: header | occ | vm | comps | pins
     d.offOcc = HDR_BYTES;
     d.offVm = d.offOcc + d.H * d.WW * 8;
@@ -1396,12 +1517,10 @@ extern "C" int pcbenv_create(const pcbenv_config *cfg, int device, pcbenv **out)
     d.ldsSeg = d.ldsCls;
     {
         const int beam = (is_pin_kind(c.kind) && c.reward_type != PCBENV_REWARD_CENTROID) ? BEAM_LDS_BYTES(c.max_num_nets, c.reward_beam_width) : 0;
-        int cls = c.kind == PCBENV_SPATIAL ? d.H * d.W : 0, seg = is_pin_kind(c.kind) ? SEG_LDS_BYTES(d.P, beam) : 0;
+        int cls = c.kind == PCBENV_SPATIAL ? d.H * d.W : 0, seg = is_pin_kind(c.kind) ? SEG_LDS_BYTES(d.P, env->threads / 64, beam) : 0;
         d.ldsBytes = align16(d.ldsCls + (cls > seg ? cls : seg));
     }
-    // threads per environment: one wave up to 64x64 cells of output per plane, four waves above
-    env->threads = c.threads_per_env == 64 || c.threads_per_env == 256 ? c.threads_per_env
-                   : ((long long)c.height * c.width * (c.kind == PCBENV_SPATIAL ? d.K + 5 : 5) > 64 * 1024 ? 256 : 64);
+    { const char *ev = getenv("PCBENV_LDS_MIN"); if (ev && atoi(ev) > d.ldsBytes) d.ldsBytes = align16(atoi(ev)); }  // occupancy experiments
     DeviceGuard guard_(device);
     if (!guard_.ok) { int r = fail(0, PCBENV_EHIP, "hipSetDevice failed (no such device?)"); delete env; return r; }
     size_t sbytes = (size_t)d.stateStride * d.B, qbytes = (size_t)d.instStride * d.B * d.Q;
@@ -1410,6 +1529,9 @@ extern "C" int pcbenv_create(const pcbenv_config *cfg, int device, pcbenv **out)
         pcbenv_destroy(env);
         return r;
     }
+#ifdef PCBENV_STAMPS
+    { const char *ev = getenv("PCBENV_STAMPS"); if (ev && ev[0] == '1') { hipMalloc((void **)&d.dbg, (size_t)d.B * 32 * 8); hipMemset(d.dbg, 0, (size_t)d.B * 32 * 8); } }
+#endif
     hipMemset(d.state, 0, sbytes);
     hipMemset(d.queue, 0, qbytes ? qbytes : 16);
     hipDeviceSynchronize();
@@ -1628,3 +1750,11 @@ extern "C" int pcbenv_queue_cursors(pcbenv *env, uint32_t *min_out, uint32_t *ma
     *min_out = host[0]; *max_out = host[1];
     return PCBENV_OK;
 }
+
+#ifdef PCBENV_STAMPS
+extern "C" int pcbenv_debug_stamps(pcbenv *env, unsigned long long *host) {  // diagnostic build only
+    if (!env || !env->dp.dbg) return -1;
+    hipDeviceSynchronize();
+    return hipMemcpy(host, env->dp.dbg, (size_t)env->dp.B * 32 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
+}
+#endif

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Phase profile of k_step from in-kernel s_memtime stamps (diagnostic build, never the shipped library):
+
+    hipcc ... -DPCBENV_STAMPS -o /tmp/libpcbenv_stamps.so csrc/pcbenv_kernels.hip csrc/instance_gen.cpp
+    PCBENV_STAMPS=1 PCBENV_LIB=/tmp/libpcbenv_stamps.so python tools/kernel_stamps.py [c3|c4]
+
+Prints, for one launch without and one with terminal environments (episodes in lockstep) and for one launch with
+staggered episode phases: the launch timeline from s_memrealtime (100 MHz) and the median shader cycles per phase."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rl-environment-for-component-placement_amd"))
+import torch  # noqa: E402
+from pcbenv import named_config  # noqa: E402
+from pcbenv.batched_env import BatchedPlacementEnv  # noqa: E402
+
+name = sys.argv[1] if len(sys.argv) > 1 else "c3"
+cfg = named_config(name)
+B, L = int(sys.argv[2]) if len(sys.argv) > 2 else 4096, cfg.max_num_components
+TERM = [("load", 0, 1), ("sample", 1, 2), ("update", 2, 3), ("fold+emit", 3, 4), ("reward:offsets+centroids", 4, 5),
+        ("reward:segments", 5, 6), ("reward:terms+prefix", 6, 22), ("reward:pair walk", 12, 13), ("reward:tail batch", 13, 14),
+        ("reward:reduce", 14, 15), ("reward:wirelength", 15, 8), ("reset:instance+Q1", 9, 16), ("reset:fold+emit", 16, 17),
+        ("reset:component features", 17, 18), ("reset:pin features", 18, 19), ("reset:rest", 19, 10), ("presample", 10, 20),
+        ("store state", 20, 11)]
+NONT = [("load", 0, 1), ("sample", 1, 2), ("update", 2, 3), ("fold+emit", 3, 4), ("rest", 4, 10), ("presample", 10, 20),
+        ("store state", 20, 11)]
+
+
+def report(title, s, done):
+    a, b = s[:, 30], s[:, 31]  # s_memrealtime at wave start / end
+    q = lambda v, f: float(np.quantile(v - a.min(), f)) * 10e-3
+    clk = np.median((s[:, 11] - s[:, 0]) / np.maximum(b - a, 1)) * 100.0
+    print(f"{title}: {int(done.sum())} terminal environments; presampled action used by {int((s[:, 21] > s[:, 0]).sum())}")
+    print(f"  wave starts p50/max {q(a, .5):.2f}/{q(a, 1):.2f} us, ends p1/p50/p99/max {q(b, .01):.2f}/{q(b, .5):.2f}/"
+          f"{q(b, .99):.2f}/{q(b, 1):.2f} us, median wave {np.median(b - a) * 10e-3:.2f} us, shader clock ~{clk:.0f} MHz")
+    for label, rows, table in (("terminal", s[done], TERM), ("non-terminal", s[~done], NONT)):
+        if len(rows):
+            print(f"  {label}: total {int(np.median(rows[:, 11] - rows[:, 0]))} cycles")
+            for n, x, y in table:
+                print(f"    {n:28s} {int(np.median(rows[:, y] - rows[:, x])):7d}")
+
+
+for stagger in (False, True):
+    env = BatchedPlacementEnv(cfg, B, queue_depth=2, auto_reset=True)
+    env.generate_instances(); env.reset()
+    env._L.pcbenv_debug_stamps.argtypes = [C.c_void_p, C.c_void_p]
+    acts = torch.empty((B, 3), dtype=torch.int32, device="cuda")
+    idx = torch.arange(B, device="cuda")
+    for t in range(2 * L):
+        env.rollout_step(t, out=acts)
+        if stagger and t < L:
+            env.reset((idx % L == t).to(torch.uint8))
+    seen = set()
+    for k in range(3 * L):
+        env.rollout_step(100 + k, out=acts)
+        torch.cuda.synchronize()
+        done = env.done.cpu().numpy().astype(bool)
+        kind = "staggered" if stagger else ("lockstep, terminal launch" if done.any() else "lockstep, non-terminal launch")
+        if k < 2 or kind in seen:
+            continue
+        seen.add(kind)
+        buf = np.zeros((B, 32), np.uint64)
+        assert env._L.pcbenv_debug_stamps(env._h, buf.ctypes.data) == 0
+        report(f"{name} x{B} {kind}", buf.astype(np.int64), done)
+    env.close()

@@ -163,7 +163,9 @@ __device__ inline void STORE16(uint4 *p, uint4 v) { __builtin_nontemporal_store(
 #endif
 __device__ inline void STORE16(uint4 *p, uint4 v) {
     v4u w{v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off " PCB_STR(PCBENV_STORE_ASM) :: "v"(p), "v"(w) : "memory");
+    // s_nop: a store wider than 64 bits may read its data VGPRs up to two wait states after issue (gfx940+ VMEM store-data
+    // hazard); the compiler pads that for its own stores but cannot see into this statement.
+    asm volatile("global_store_dwordx4 %0, %1, off " PCB_STR(PCBENV_STORE_ASM) "\n\ts_nop 1" :: "v"(p), "v"(w) : "memory");
 }
 #endif
 
@@ -825,6 +827,8 @@ template <int WW> __device__ inline void emit_pin_grid(const DevParams &p, Lds &
     if (!p.buf.pin_grid) return;
     const int W = p.W, HW = p.H * W, K = p.K;
     const int c0 = r0 * W, c1 = r1 * W;
+    unsigned char *dst = p.buf.pin_grid + (size_t)e * HW * K;
+    const long long b0 = (long long)c0 * K, b1 = (long long)c1 * K;
     for (int i = c0 + lane; i < c1; i += NT) {
         int r = i / W, c = i - r * W;
         l.cls[i] = (unsigned char)((l.occ[r * WW + (c >> 6)] >> (c & 63)) & 1ull);
@@ -835,8 +839,6 @@ template <int WW> __device__ inline void emit_pin_grid(const DevParams &p, Lds &
         if (pr.abs_x >= r0 && pr.abs_x < r1 && pr.abs_y >= 0) l.cls[pr.abs_x * W + pr.abs_y] = (unsigned char)(pr.net + 2);
     }
     lds_sync();
-    unsigned char *dst = p.buf.pin_grid + (size_t)e * HW * K;
-    const long long b0 = (long long)c0 * K, b1 = (long long)c1 * K;
     if ((b0 & 15) == 0 && (b1 & 15) == 0 && (((uintptr_t)dst) & 15) == 0) {
         uint4 *d4 = (uint4 *)dst;
         // every cell owns K consecutive bytes with at most one 1 (at class-1): visit the <= 16/K + 2 cells a
@@ -987,11 +989,33 @@ template <int KIND, int WW> __device__ inline void reset_env(const DevParams &p,
     // The float64 pin-feature tensors are maintained row-wise (a step rewrites only the placed component's
     // rows), so a reset clears just the rows the finished episode used -- unless these buffers have not been
     // initialised for this environment yet (first reset after pcbenv_bind_buffers): then a full zero fill.
+    // Rows of the finished episode that the new episode rewrites are left alone (no write-after-write on a row, so
+    // no ordering wait between the clear and the later row writes): spatial rows are the pin ids 0..np-1; the pin
+    // env's rows [component, pin_id] go through a membership bit map in the fold scratch.
+    InstRegs ir;
+    if (KIND != PCBENV_SQUARE) fetch_instance(p, l.hdr->qcursor, e, lane, ir);
     bool rows_cleared = false;
-    if ((KIND == PCBENV_PIN || KIND == PCBENV_SPATIAL) && l.hdr->feat_gen == p.bind_gen) {
+    if ((KIND == PCBENV_PIN || KIND == PCBENV_SPATIAL) && l.hdr->feat_gen == p.bind_gen &&
+        (KIND == PCBENV_SPATIAL || p.C * p.mp <= H * WW * 64)) {
+        u64 *rowbits = l.hf;
+        if (KIND == PCBENV_PIN) {
+            for (int i = lane; i < H * WW; i += NT) rowbits[i] = 0ull;
+            lds_sync();
+            #pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int q = lane + r * NT;
+                if (q < ir.np && q < p.P) {
+                    const u64 w = ir.pin[r];
+                    const int row = (int)((w >> 24) & 0xFF) * p.mp + (int)((w >> 32) & PIN_ID_MASK);
+                    atomicOr((unsigned long long *)&rowbits[row >> 6], 1ull << (row & 63));
+                }
+            }
+            lds_sync();
+        }
         for (int q = lane; q < l.hdr->npins; q += NT) {
             const PinRec pr = l.pins[q];
             const int row = KIND == PCBENV_SPATIAL ? (pr.id & PIN_ID_MASK) : pr.comp * p.mp + (pr.id & PIN_ID_MASK);
+            if (KIND == PCBENV_SPATIAL ? row < ir.np : (int)((rowbits[row >> 6] >> (row & 63)) & 1ull)) continue;
             if (p.buf.all_pins_num_feature) {
                 double *f = p.buf.all_pins_num_feature + ((size_t)e * p.pinRows + row) * 4;
                 f[0] = 0.0; f[1] = 0.0; f[2] = 0.0; f[3] = 0.0;
@@ -1006,8 +1030,6 @@ template <int KIND, int WW> __device__ inline void reset_env(const DevParams &p,
     lds_sync();
     for (int i = lane; i < H * WW; i += NT) l.occ[i] = 0ull;
     if (KIND != PCBENV_SQUARE) {
-        InstRegs ir;
-        fetch_instance(p, l.hdr->qcursor, e, lane, ir);
         const int nc = ir.nc, nn = ir.nn, np = ir.np;
         if (lane < p.C) {
             const u64 w = ir.comp;
@@ -1082,6 +1104,24 @@ template <int KIND, int WW> __device__ inline void reset_env(const DevParams &p,
     if (KIND != PCBENV_SQUARE) {
         const int nc = l.hdr->ncomp, np = l.hdr->npins;
         // all_components_feature (R:60-79, S:203-239): [h, w, -1, -1, area/(H*W), (spatial: pin ids, -1 pad)]; absent rows 0
+        // spatial scratch in the class-map zone (free until the next emit_pin_grid): pid[c][k] = id of the k-th pin
+        // of component c in self.pins order (0xFFFF = none), netmask[c][rel_x][rel_y] = nets with a pin on that cell
+        unsigned short *pid = (unsigned short *)l.cls;
+        unsigned *netmask = (unsigned *)(l.cls + ((p.C * p.mp * 2 + 3) & ~3));
+        if (KIND == PCBENV_SPATIAL) {
+            for (int i = lane; i < p.C * p.mp; i += NT) { pid[i] = 0xFFFFu; netmask[i] = 0u; }
+            lds_sync();
+            for (int q = lane; q < np; q += NT) {
+                const PinRec pr = l.pins[q];
+                int rank = 0;
+                #pragma unroll 4
+                for (int q2 = 0; q2 < np; q2++) rank += (q2 < q) & (l.pins[q2].comp == pr.comp);  // broadcast reads
+                pid[pr.comp * p.mp + rank] = (unsigned short)(pr.id & PIN_ID_MASK);
+                atomicOr(&netmask[(int)pr.comp * p.mp + pr.rel_x * p.mw + pr.rel_y], 1u << pr.net);
+            }
+            lds_sync();
+        }
+        // all_components_feature (R:60-79, S:203-239): [h, w, -1, -1, area/(H*W), (spatial: pin ids, -1 pad)]; absent rows 0
         if (p.buf.all_components_feature) {
             double *cf = p.buf.all_components_feature + (size_t)e * p.C * p.F;
             for (int i = lane; i < p.C * p.F; i += NT) {
@@ -1090,17 +1130,13 @@ template <int KIND, int WW> __device__ inline void reset_env(const DevParams &p,
                 if (c < nc) {
                     const CompRec cr = l.comps[c];
                     if (k == 0) v = cr.h; else if (k == 1) v = cr.w; else if (k == 2 || k == 3) v = -1.0;
-                    else if (k == 4) v = (double)(cr.h * cr.w) / p.area; else v = -1.0;
+                    else if (k == 4) v = (double)(cr.h * cr.w) / p.area;
+                    else {
+                        const unsigned id = KIND == PCBENV_SPATIAL ? pid[c * p.mp + k - 5] : 0xFFFFu;
+                        v = id == 0xFFFFu ? -1.0 : (double)id;
+                    }
                 }
                 cf[i] = v;
-            }
-            if (KIND == PCBENV_SPATIAL) {  // pin ids of component.pins (self.pins order)
-                __syncthreads();  // also orders this thread block's global stores (zero fill before the row writes)
-            __threadfence_block();
-                for (int c = lane; c < nc; c += NT) {
-                    int k = 0;
-                    for (int q = 0; q < np; q++) if (l.pins[q].comp == c) cf[c * p.F + 5 + k++] = (double)(l.pins[q].id & PIN_ID_MASK);
-                }
             }
         }
         STAMP(18);
@@ -1124,8 +1160,10 @@ template <int KIND, int WW> __device__ inline void reset_env(const DevParams &p,
                     f[i] = (KIND == PCBENV_SPATIAL && i >= (p.pinRows - 1) * p.catW) ? -1.0 : 0.0;  // S:1520
             }
             if (lane == 0) l.hdr->feat_gen = p.bind_gen;
-            __syncthreads();  // also orders this thread block's global stores (zero fill before the row writes)
-            __threadfence_block();
+            if (!rows_cleared) {  // first reset after a bind: the full zero fill above must land before the row writes
+                __syncthreads();
+                __threadfence_block();
+            }
             for (int q = lane; q < np; q += NT) {
                 const PinRec pr = l.pins[q];
                 write_pin_num<KIND>(p, e, pr);
@@ -1143,17 +1181,28 @@ template <int KIND, int WW> __device__ inline void reset_env(const DevParams &p,
         if (KIND == PCBENV_SPATIAL) {
             if (p.buf.pin_grid) emit_zero(p.buf.pin_grid + (size_t)e * HW * p.K, (long long)HW * p.K, lane);  // S:1504
             if (p.buf.component_grid) {  // S:1677-1697 draw_components (unrotated rel coords; channel 0 == 1)
-                const int cgsz = p.mh * p.mw * p.K;
-                unsigned char *cg = p.buf.component_grid + (size_t)e * p.C * cgsz;
-                for (int i = lane; i < p.C * cgsz; i += NT) {
-                    const int c = i / cgsz, k = i % p.K;
-                    cg[i] = (unsigned char)(c < nc && k == 0);
-                }
-                __syncthreads();  // also orders this thread block's global stores (zero fill before the row writes)
-            __threadfence_block();
-                for (int q = lane; q < np; q += NT) {
-                    const PinRec pr = l.pins[q];
-                    cg[((size_t)pr.comp * p.mh * p.mw + pr.rel_x * p.mw + pr.rel_y) * p.K + pr.net + 1] = 1;
+                const int cells = p.mh * p.mw, cgsz = cells * p.K, total = p.C * cgsz;
+                unsigned char *cg = p.buf.component_grid + (size_t)e * total;
+                // byte (cell, ch) = ch == 0 ? component exists : net ch-1 has a pin on the cell; each byte written once
+                if ((total & 15) == 0 && (((uintptr_t)cg) & 15) == 0) {
+                    for (int c16 = lane; c16 < total / 16; c16 += NT) {
+                        const int bb = c16 * 16;
+                        int cell = bb / p.K, ch = bb - cell * p.K;
+                        u64 field = ((u64)netmask[cell] << 1) | (u64)(cell / cells < nc);  // bit ch = byte value of channel ch
+                        u64 lo = 0ull, hi = 0ull;
+                        #pragma unroll
+                        for (int k = 0; k < 16; k++) {
+                            const u64 bit = (field >> ch) & 1ull;
+                            if (k < 8) lo |= bit << (8 * k); else hi |= bit << (8 * (k - 8));
+                            if (++ch == p.K) { ch = 0; cell++; field = cell < p.C * cells ? (((u64)netmask[cell] << 1) | (u64)(cell / cells < nc)) : 0ull; }
+                        }
+                        STORE16((uint4 *)cg + c16, make_uint4((unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)));
+                    }
+                } else {
+                    for (int i = lane; i < total; i += NT) {
+                        const int cell = i / p.K, ch = i - cell * p.K;
+                        cg[i] = (unsigned char)(ch == 0 ? (cell / cells < nc) : ((netmask[cell] >> (ch - 1)) & 1u));
+                    }
                 }
             }
         }
@@ -1314,6 +1363,7 @@ __global__ __launch_bounds__(64 * NW) void k_step(DevParams p, int *__restrict__
     const int r0 = inc ? x : 0, r1 = inc ? min(x + ph, H) : H;
     const bool skip_emit = auto_reset && KIND != PCBENV_SQUARE && l.hdr->cur < 0;
     const bool any = mask_and_emit<KIND, WW>(p, l, e, lane, !skip_emit, r0, r1);
+    STAMP(23);
     if (KIND == PCBENV_SPATIAL && !skip_emit) emit_pin_grid<WW>(p, l, e, lane, r0, r1);
     STAMP(4);
     const bool done = KIND == PCBENV_SQUARE ? !any : (l.hdr->cur < 0 || !any);  // S:1856-1869
@@ -1517,7 +1567,8 @@ extern "C" int pcbenv_create(const pcbenv_config *cfg, int device, pcbenv **out)
     d.ldsSeg = d.ldsCls;
     {
         const int beam = (is_pin_kind(c.kind) && c.reward_type != PCBENV_REWARD_CENTROID) ? BEAM_LDS_BYTES(c.max_num_nets, c.reward_beam_width) : 0;
-        int cls = c.kind == PCBENV_SPATIAL ? d.H * d.W : 0, seg = is_pin_kind(c.kind) ? SEG_LDS_BYTES(d.P, env->threads / 64, beam) : 0;
+        // class map of emit_pin_grid; at a reset the same zone holds the pin-id and net-mask tables (2 + 4 bytes per component cell)
+        int cls = c.kind == PCBENV_SPATIAL ? (d.H * d.W > d.C * d.mp * 6 + 4 ? d.H * d.W : d.C * d.mp * 6 + 4) : 0, seg = is_pin_kind(c.kind) ? SEG_LDS_BYTES(d.P, env->threads / 64, beam) : 0;
         d.ldsBytes = align16(d.ldsCls + (cls > seg ? cls : seg));
     }
     { const char *ev = getenv("PCBENV_LDS_MIN"); if (ev && atoi(ev) > d.ldsBytes) d.ldsBytes = align16(atoi(ev)); }  // occupancy experiments

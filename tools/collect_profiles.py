@@ -16,15 +16,15 @@ for f in glob.glob(f"{src}/*_bench.json"):
     if lines:
         open(os.path.join(dst, os.path.basename(f)), "w").write(lines[-1])
 for cfg in ("c2", "c3", "c4", "c5"):
-    st = glob.glob(f"{src}/prof_{cfg}/*/*kernel_stats.csv")
+    st = sorted(glob.glob(f"{src}/prof_{cfg}/*/*kernel_stats.csv"), key=os.path.getmtime)  # newest run
     if st:
-        shutil.copy(st[0], f"{dst}/{cfg}_kernel_stats.csv")
+        shutil.copy(st[-1], f"{dst}/{cfg}_kernel_stats.csv")
     out = {}
     for name, tag in (("WRITE_SIZE", "pmcw"), ("FETCH_SIZE", "pmcf")):
-        fs = glob.glob(f"{src}/{tag}_{cfg}/*/*counter_collection.csv")
+        fs = sorted(glob.glob(f"{src}/{tag}_{cfg}/*/*counter_collection.csv"), key=os.path.getmtime)  # newest run
         if not fs:
             continue
-        rows = [r for r in csv.DictReader(open(fs[0])) if "k_step" in r["Kernel_Name"]]
+        rows = [r for r in csv.DictReader(open(fs[-1])) if "k_step" in r["Kernel_Name"]]
         v = [float(r["Counter_Value"]) for r in rows]
         if v:
             out[name] = {"dispatches": len(v), "mean_KiB": sum(v) / len(v), "min_KiB": min(v), "max_KiB": max(v)}

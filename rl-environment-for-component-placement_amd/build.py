@@ -11,7 +11,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 SRC = [os.path.join(HERE, "csrc", "pcbenv_kernels.hip"), os.path.join(HERE, "csrc", "instance_gen.cpp")]
-DEPS = SRC + [os.path.join(REPO, "include", "pcbenv.h")]
+DEPS = SRC + [os.path.join(REPO, "include", "pcbenv.h")] + sorted(
+    os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc")) if f.endswith(".h"))
 OUT = os.path.join(HERE, "libpcbenv.so")
 
 

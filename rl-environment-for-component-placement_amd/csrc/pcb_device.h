@@ -1,0 +1,221 @@
+// pcb_device.h -- device-side parameter block, state-block records, LDS barrier, bit rows, 16-byte plane emission, wave scan
+// Part of libpcbenv.so's single translation unit (included by pcbenv_kernels.hip); CDNA4 / gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "pcbenv.h"
+
+typedef unsigned long long u64;
+
+#define WAVE 64
+#define NT ((int)blockDim.x)   // threads per environment: 64 (one wave) or 256 (four waves, large grids)
+#define MAX_NT 256
+#define HDR_BYTES 64
+
+// ----------------------------------------------------------------------------------------------
+// device-side parameter block (kernel argument, by value)
+// ----------------------------------------------------------------------------------------------
+struct DevParams {
+    int kind, H, W, WW, O, C, P, N, K, mp, mh, mw, F, pinRows, catW, B, Q;
+    int reward_type, beam_width, component_n;
+    unsigned flags, bind_gen;
+    double w_wl, w_int, max_wl, max_int, wl_norm, int_norm, area;
+    long long stateStride, instStride;
+    int offOcc, offVm, offComps, offPins;   // byte offsets inside a state block
+    int ldsHf, ldsCls, ldsSeg, ldsBytes;    // byte offsets of LDS scratch behind the state mirror
+    unsigned char *state, *queue;
+    pcbenv_buffers buf;
+    unsigned long long *dbg;                // diagnostic build only (-DPCBENV_STAMPS): [B][32] s_memtime stamps
+};
+// In-kernel stamps (cdna_hip_programming.md §7): only in a separate diagnostic build, written to a buffer nothing
+// else reads; `PCBENV_STAMPS=1` in the environment allocates it, tools/kernel_stamps.py prints the phase profile.
+#ifdef PCBENV_STAMPS
+#define STAMP(k) do { if (threadIdx.x == 0 && p.dbg) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); p.dbg[(size_t)blockIdx.x * 32 + (k)] = t_; } } while (0)
+#define STAMP_RT(k) do { if (threadIdx.x == 0 && p.dbg) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); p.dbg[(size_t)blockIdx.x * 32 + (k)] = t_; } } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#define STAMP_RT(k) do { } while (0)
+#endif
+
+// per-environment header at the start of a state block
+struct __attribute__((aligned(16))) EnvHdr {
+    short ncomp, nnets, npins, cur;  // cur = index of the current component, -1 = sentinel (all placed)
+    unsigned episode;                // completed resets
+    unsigned qcursor;                // next queue slot
+    unsigned flag;                   // LDS scratch word: workgroup-wide any(), and y of the sampled action
+    unsigned pad[2];                 // LDS scratch: (o, x) of the action drawn by wavefront 0 (fused sampler)
+    unsigned feat_gen;               // bind generation for which the pin-feature tensors hold only this env's rows
+    // Action of the NEXT fused-sampler step, drawn at the end of the launch that produced the mask (while its
+    // stores drain) instead of at the head of the next launch, where the whole grid would wait for it.  Valid
+    // (bit 31 of pre_action) only for exactly this (seed, step index, global env index) and only while vm is the
+    // mask it was drawn from: every launch that rewrites vm redraws or clears it.
+    u64 pre_seed, pre_step;
+    unsigned pre_action;             // o | x << 8 | y << 16 | 1 << 31
+    unsigned pre_genv;
+    unsigned rsv[2];
+};
+static_assert(sizeof(EnvHdr) == HDR_BYTES, "header size");
+
+// 8-byte records (state block and instance wire format share the pin layout up to abs_x/abs_y)
+struct CompRec { unsigned char h, w; signed char px, py; unsigned char pad[4]; };
+struct PinRec { unsigned char rel_x, rel_y; signed char abs_x, abs_y; unsigned char net, comp; unsigned short id; };
+#define PIN_ID_MASK 0x7FFF
+#define PIN_LOSER 0x8000  // pin env quirk Q1: a later pin of the same component shares this feature row
+
+// Workgroup barrier that waits for LDS traffic only.  __syncthreads() also drains the global stores in flight
+// (s_waitcnt vmcnt(0)), which would serialise the observation write stream between kernel phases.
+__device__ inline void lds_sync() {
+#ifdef PCBENV_FULL_SYNC
+    __syncthreads();
+    return;
+#endif
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+// any() over the workgroup; `flag` is an LDS word
+__device__ inline bool block_any(bool v, unsigned *flag) {
+    if (NT == WAVE) return __any(v);
+    if (threadIdx.x == 0) *flag = 0;
+    lds_sync();
+    if (__any(v) && (threadIdx.x & 63) == 0) *flag = 1;
+    lds_sync();
+    return *flag != 0;
+}
+
+// ----------------------------------------------------------------------------------------------
+// bit rows
+// ----------------------------------------------------------------------------------------------
+template <int WW> struct Row;
+template <> struct Row<1> {
+    u64 a;
+    __device__ static Row load(const u64 *p) { return Row{p[0]}; }
+    __device__ void store(u64 *p) const { p[0] = a; }
+    __device__ Row operator|(Row o) const { return Row{a | o.a}; }
+    __device__ Row shr(int k) const { return Row{k >= 64 ? 0ull : a >> k}; }
+    __device__ static Row zero() { return Row{0ull}; }
+    __device__ bool any() const { return a != 0; }
+    // valid = ~occ restricted to columns [0, n)
+    __device__ Row free_below(int n) const { return Row{n <= 0 ? 0ull : (~a & (n >= 64 ? ~0ull : ((1ull << n) - 1ull)))}; }
+};
+template <> struct Row<2> {
+    u64 a, b;
+    __device__ static Row load(const u64 *p) { return Row{p[0], p[1]}; }
+    __device__ void store(u64 *p) const { p[0] = a; p[1] = b; }
+    __device__ Row operator|(Row o) const { return Row{a | o.a, b | o.b}; }
+    __device__ Row shr(int k) const {
+        if (k == 0) return *this;
+        if (k >= 128) return Row{0ull, 0ull};
+        if (k >= 64) return Row{b >> (k - 64), 0ull};
+        return Row{(a >> k) | (b << (64 - k)), b >> k};
+    }
+    __device__ static Row zero() { return Row{0ull, 0ull}; }
+    __device__ bool any() const { return (a | b) != 0; }
+    __device__ Row free_below(int n) const {
+        u64 ma = n <= 0 ? 0ull : (n >= 64 ? ~0ull : ((1ull << n) - 1ull));
+        u64 mb = n <= 64 ? 0ull : (n >= 128 ? ~0ull : ((1ull << (n - 64)) - 1ull));
+        return Row{~a & ma, ~b & mb};
+    }
+};
+
+// OR_{k < pw} (row >> k): bit j set iff some cell j..j+pw-1 of the row is occupied (log-step doubling).
+template <int WW> __device__ inline Row<WW> hfold(Row<WW> r, int pw) {
+    Row<WW> f = r;
+    int s = 1;
+    while (2 * s <= pw) { f = f | f.shr(s); s *= 2; }
+    if (s < pw) f = f | f.shr(pw - s);
+    return f;
+}
+
+// 16-byte observation / state store, agent-scope write-through (`sc1`): every line written here is next read by
+// another launch (usually on another XCD) or by the policy, never by this workgroup, so leaving it dirty in the
+// XCD's L2 only defers the write to the end-of-kernel release, where the whole grid waits for it (+5 % at c3).
+// -DPCBENV_STORE_PLAIN / -DPCBENV_NT_STORES / -DPCBENV_STORE_ASM="..." keep the alternatives for A/B runs.
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+#define PCB_STR_(x) #x
+#define PCB_STR(x) PCB_STR_(x)
+#if defined(PCBENV_STORE_PLAIN)
+__device__ inline void STORE16(uint4 *p, uint4 v) { *p = v; }
+#elif defined(PCBENV_NT_STORES)
+__device__ inline void STORE16(uint4 *p, uint4 v) { __builtin_nontemporal_store(v4u{v.x, v.y, v.z, v.w}, (v4u *)p); }
+#else
+#ifndef PCBENV_STORE_ASM
+#define PCBENV_STORE_ASM sc1
+#endif
+__device__ inline void STORE16(uint4 *p, uint4 v) {
+    v4u w{v.x, v.y, v.z, v.w};
+    // s_nop: a store wider than 64 bits may read its data VGPRs up to two wait states after issue (gfx940+ VMEM store-data
+    // hazard); the compiler pads that for its own stores but cannot see into this statement.
+    asm volatile("global_store_dwordx4 %0, %1, off " PCB_STR(PCBENV_STORE_ASM) "\n\ts_nop 1" :: "v"(p), "v"(w) : "memory");
+}
+#endif
+
+// 4 mask bits -> 4 bytes of 0/1
+__device__ inline unsigned expand4(unsigned b) { return (b * 0x00204081u) & 0x01010101u; }
+__device__ inline uint4 expand16(unsigned bits) {
+    return make_uint4(expand4(bits & 15u), expand4((bits >> 4) & 15u), expand4((bits >> 8) & 15u), expand4((bits >> 12) & 15u));
+}
+
+// Write one H x W uint8 plane (0/1) from bit rows in LDS: 16 bytes per lane, 1 KiB per wave instruction.
+// Rows [r0, r1) only (full plane: 0, H).
+template <int WW> __device__ inline void emit_plane(unsigned char *dst, const u64 *bits, int r0, int r1, int W, int lane) {
+    if ((W & 15) == 0 && (((uintptr_t)dst) & 15) == 0) {
+        uint4 *d4 = (uint4 *)dst;
+        const int sh = (W & (W - 1)) == 0 ? __ffs(W) - 1 : -1;
+        for (int c = r0 * W / 16 + lane; c < r1 * W / 16; c += NT) {
+            int cell = c * 16, r = sh >= 0 ? cell >> sh : cell / W, col = cell - r * W;
+            unsigned b = (unsigned)(bits[r * WW + (col >> 6)] >> (col & 63)) & 0xFFFFu;
+            STORE16(d4 + c, expand16(b));
+        }
+    } else {  // odd widths (the reference's small test grids): byte path
+        for (int i = r0 * W + lane; i < r1 * W; i += NT) {
+            int r = i / W, col = i - r * W;
+            dst[i] = (unsigned char)((bits[r * WW + (col >> 6)] >> (col & 63)) & 1ull);
+        }
+    }
+}
+__device__ inline void emit_zero(unsigned char *dst, long long bytes, int lane) {
+    if ((bytes & 15) == 0 && (((uintptr_t)dst) & 15) == 0) {
+        uint4 *d4 = (uint4 *)dst;
+        for (long long c = lane; c < bytes / 16; c += NT) STORE16(d4 + c, make_uint4(0, 0, 0, 0));
+    } else {
+        for (long long i = lane; i < bytes; i += NT) dst[i] = 0;
+    }
+}
+
+// Legal-placement bit mask for a ph x pw window (R:526-567, S:1792-1835):
+// vm[r] bit j = 1 iff r <= H-ph and j <= W-pw and occ[r..r+ph-1][j..j+pw-1] is empty.
+// Returns (wave-uniform) whether any bit is set.
+template <int WW>
+__device__ inline bool window_mask(const u64 *occ, u64 *hf, u64 *vm, int H, int W, int ph, int pw, int lane, unsigned *flag) {
+    for (int r = lane; r < H; r += NT) hfold<WW>(Row<WW>::load(occ + r * WW), pw).store(hf + r * WW);
+    lds_sync();
+    bool any = false;
+    for (int r = lane; r < H; r += NT) {
+        Row<WW> v = Row<WW>::zero();
+        if (r + ph <= H) {
+            Row<WW> acc = Row<WW>::load(hf + r * WW);
+            for (int k = 1; k < ph; k++) acc = acc | Row<WW>::load(hf + (r + k) * WW);
+            v = acc.free_below(W - pw + 1);
+        }
+        v.store(vm + r * WW);
+        any |= v.any();
+    }
+    return block_any(any, flag);
+}
+
+// Inclusive prefix sum over the 64 lanes with DPP row shifts / row broadcasts (no LDS round trips).
+__device__ inline int wave_inclusive_scan(int x, int lane) {
+    const int row = lane & 15;
+    int t;
+    t = __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false); if (row >= 1) x += t;   // row_shr:1
+    t = __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false); if (row >= 2) x += t;   // row_shr:2
+    t = __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false); if (row >= 4) x += t;   // row_shr:4
+    t = __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false); if (row >= 8) x += t;   // row_shr:8
+    t = __builtin_amdgcn_update_dpp(0, x, 0x142, 0xF, 0xF, false); if ((lane & 31) >= 16) x += t;  // row_bcast:15
+    t = __builtin_amdgcn_update_dpp(0, x, 0x143, 0xF, 0xF, false); if (lane >= 32) x += t;         // row_bcast:31
+    return x;
+}
+

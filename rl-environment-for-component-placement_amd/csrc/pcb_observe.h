@@ -1,0 +1,175 @@
+// pcb_observe.h -- state block staging through LDS, legal-mask fold + observation emission, pin_grid, feature rows, terminal reward
+// Part of libpcbenv.so's single translation unit (included by pcbenv_kernels.hip); CDNA4 / gfx950 only.
+#pragma once
+#include "pcb_beam.h"
+
+// ----------------------------------------------------------------------------------------------
+// shared pieces of reset / step
+// ----------------------------------------------------------------------------------------------
+struct Lds {
+    EnvHdr *hdr; u64 *occ, *vm; CompRec *comps; PinRec *pins;
+    u64 *hf; unsigned char *cls; double *seg;
+};
+__device__ inline Lds carve(unsigned char *smem, const DevParams &p) {
+    Lds l;
+    l.hdr = (EnvHdr *)smem;
+    l.occ = (u64 *)(smem + p.offOcc);
+    l.vm = (u64 *)(smem + p.offVm);
+    l.comps = (CompRec *)(smem + p.offComps);
+    l.pins = (PinRec *)(smem + p.offPins);
+    l.hf = (u64 *)(smem + p.ldsHf);
+    l.cls = smem + p.ldsCls;
+    l.seg = (double *)(smem + p.ldsSeg);
+    return l;
+}
+__device__ inline void load_state(unsigned char *smem, const DevParams &p, int e, int lane) {
+    const uint4 *src = (const uint4 *)(p.state + (size_t)e * p.stateStride);
+    uint4 *dst = (uint4 *)smem;
+    for (int i = lane; i < (int)(p.stateStride / 16); i += NT) dst[i] = src[i];
+    lds_sync();
+}
+__device__ inline void store_state(const unsigned char *smem, const DevParams &p, int e, int lane) {
+    lds_sync();
+    uint4 *dst = (uint4 *)(p.state + (size_t)e * p.stateStride);
+    const uint4 *src = (const uint4 *)smem;
+    // plain write-back stores: environment e runs on XCD e % 8 in every launch, so its state block is an L2 hit next step
+    for (int i = lane; i < (int)(p.stateStride / 16); i += NT) dst[i] = src[i];
+}
+
+// Marginals of the legal mask for factorised policies (factorized_action_distributions.py:358, :401): per
+// orientation "any legal cell" and per (orientation, row) "any legal column", read off the bit rows in LDS.
+template <int KIND, int WW> __device__ inline void emit_marginals(const DevParams &p, Lds &l, int e, int lane) {
+    if (!p.buf.mask_rows && !p.buf.mask_orientation) return;
+    const int H = p.H, plane = H * WW, O = p.O;
+    for (int i = lane; i < O * H; i += NT) {
+        const int o = i / H, r = i - o * H;
+        const u64 *row = l.vm + (o & 1) * plane + r * WW;
+        bool a = false;
+        for (int w = 0; w < WW; w++) a |= row[w] != 0;
+        if (p.buf.mask_rows) p.buf.mask_rows[(size_t)e * O * H + i] = a ? 1 : 0;
+    }
+    if (p.buf.mask_orientation) {
+        for (int o = (int)(lane / WAVE); o < O; o += NT / WAVE) {  // one wavefront per orientation
+            bool a = false;
+            for (int i = (lane & 63); i < plane; i += WAVE) a |= l.vm[(o & 1) * plane + i] != 0;
+            a = __any(a);
+            if ((lane & 63) == 0) p.buf.mask_orientation[(size_t)e * O + o] = a ? 1 : 0;
+        }
+    }
+}
+
+// Mask of the current component (or zeros) into l.vm, both orientations, and -- when `emit` -- the grid rows
+// [gr0, gr1) and the action_mask planes, each written as soon as its bits exist so that the HBM write stream
+// starts before the second orientation is folded.  Returns "some action is legal".
+template <int KIND, int WW>
+__device__ inline bool mask_and_emit(const DevParams &p, Lds &l, int e, int lane, bool emit, int gr0, int gr1) {
+    const int H = p.H, W = p.W, HW = H * W, plane = H * WW;
+    const int cur = l.hdr->cur;
+    unsigned char *m = (emit && p.buf.action_mask) ? p.buf.action_mask + (size_t)e * p.O * HW : 0;
+    if (emit && p.buf.grid) emit_plane<WW>(p.buf.grid + (size_t)e * HW, l.occ, gr0, gr1, W, lane);
+    bool any = false;
+    if (KIND == PCBENV_SQUARE) {
+        any = window_mask<WW>(l.occ, l.hf, l.vm, H, W, p.component_n, p.component_n, lane, &l.hdr->flag);
+        if (m) emit_plane<WW>(m, l.vm, 0, H, W, lane);
+        if (emit) emit_marginals<KIND, WW>(p, l, e, lane);
+        return any;
+    }
+    const bool four = (KIND == PCBENV_PIN || KIND == PCBENV_SPATIAL);  // S:1852-1853 mask[2] = mask[0], mask[3] = mask[1]
+    if (cur >= 0) {
+        const int h = l.comps[cur].h, w = l.comps[cur].w;
+        any = window_mask<WW>(l.occ, l.hf, l.vm, H, W, h, w, lane, &l.hdr->flag);
+        if (m) { emit_plane<WW>(m, l.vm, 0, H, W, lane); if (four) emit_plane<WW>(m + 2 * HW, l.vm, 0, H, W, lane); }
+        if (h == w) {
+            for (int i = lane; i < plane; i += NT) l.vm[plane + i] = l.vm[i];
+            lds_sync();
+        } else {
+            any |= window_mask<WW>(l.occ, l.hf, l.vm + plane, H, W, w, h, lane, &l.hdr->flag);
+        }
+    } else {
+        for (int i = lane; i < 2 * plane; i += NT) l.vm[i] = 0ull;
+        lds_sync();
+        if (m) { emit_plane<WW>(m, l.vm, 0, H, W, lane); if (four) emit_plane<WW>(m + 2 * HW, l.vm, 0, H, W, lane); }
+    }
+    if (m) { emit_plane<WW>(m + HW, l.vm + plane, 0, H, W, lane); if (four) emit_plane<WW>(m + 3 * HW, l.vm + plane, 0, H, W, lane); }
+    if (emit) emit_marginals<KIND, WW>(p, l, e, lane);
+    return any;
+}
+
+// S:1663-1675 draw_pins: class map (0 empty, 1 occupied without pin, n+2 pin of net n) -> one-hot[:, :, 1:];
+// rows [r0, r1) of the (H, W, K) tensor (a step only changes the rows of the placed rectangle).
+template <int WW> __device__ inline void emit_pin_grid(const DevParams &p, Lds &l, int e, int lane, int r0, int r1) {
+    if (!p.buf.pin_grid) return;
+    const int W = p.W, HW = p.H * W, K = p.K;
+    const int c0 = r0 * W, c1 = r1 * W;
+    unsigned char *dst = p.buf.pin_grid + (size_t)e * HW * K;
+    const long long b0 = (long long)c0 * K, b1 = (long long)c1 * K;
+    for (int i = c0 + lane; i < c1; i += NT) {
+        int r = i / W, c = i - r * W;
+        l.cls[i] = (unsigned char)((l.occ[r * WW + (c >> 6)] >> (c & 63)) & 1ull);
+    }
+    lds_sync();
+    for (int q = lane; q < l.hdr->npins; q += NT) {
+        const PinRec pr = l.pins[q];
+        if (pr.abs_x >= r0 && pr.abs_x < r1 && pr.abs_y >= 0) l.cls[pr.abs_x * W + pr.abs_y] = (unsigned char)(pr.net + 2);
+    }
+    lds_sync();
+    if ((b0 & 15) == 0 && (b1 & 15) == 0 && (((uintptr_t)dst) & 15) == 0) {
+        uint4 *d4 = (uint4 *)dst;
+        // every cell owns K consecutive bytes with at most one 1 (at class-1): visit the <= 16/K + 2 cells a
+        // 16-byte chunk overlaps and drop their 1-bytes into two 64-bit halves
+        const unsigned kinv = 0xFFFFFFFFu / (unsigned)K + 1u;  // floor(b / K) == umulhi(b, kinv) for b < 2^32 / K
+        for (int c = (int)(b0 / 16) + lane; c < (int)(b1 / 16); c += NT) {
+            const int bb = c * 16;
+            int cell = (int)__umulhi((unsigned)bb, kinv);
+            if (cell * K > bb) cell--;  // (never taken at these sizes; keeps the division exact regardless)
+            u64 lo = 0, hi = 0;
+            for (int base = cell * K; base < bb + 16 && cell < c1; base += K, cell++) {
+                const unsigned cl = l.cls[cell];
+                const int off = base + (int)cl - 1 - bb;  // byte of this cell's 1 inside the chunk
+                if (cl != 0 && off >= 0 && off < 16) {
+                    if (off < 8) lo |= 1ull << (8 * off); else hi |= 1ull << (8 * (off - 8));
+                }
+            }
+            STORE16(d4 + c, make_uint4((unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)));
+        }
+    } else {
+        for (long long i = b0 + lane; i < b1; i += NT) {
+            int cell = (int)(i / K), ch = (int)(i - (long long)cell * K);
+            dst[i] = (unsigned char)(l.cls[cell] == ch + 1);
+        }
+    }
+}
+
+// Feature rows of one pin (P:72-103 / S:70-104 Pin.calculate_feature): [rel_x, rel_y, abs_x, abs_y]
+template <int KIND> __device__ inline void write_pin_num(const DevParams &p, int e, const PinRec &pr) {
+    if (!p.buf.all_pins_num_feature) return;
+    int row;
+    if (KIND == PCBENV_SPATIAL) row = pr.id & PIN_ID_MASK;
+    else { if (pr.id & PIN_LOSER) return; row = pr.comp * p.mp + (pr.id & PIN_ID_MASK); }
+    double *f = p.buf.all_pins_num_feature + ((size_t)e * p.pinRows + row) * 4;
+    f[0] = pr.rel_x; f[1] = pr.rel_y; f[2] = pr.abs_x; f[3] = pr.abs_y;
+}
+
+// Terminal reward (S:793-929 find_reward), all three reward types, inside the step kernel.
+// ROUTES = false compiles the beam-search code out (reward_type centroid: what every shipped reference config uses).
+template <int KIND, bool ROUTES>
+__device__ inline void terminal_reward(const DevParams &p, Lds &l, int e, int lane) {
+    const bool placed_all = l.hdr->cur < 0;
+    double reward, wl, ni;
+    if (!placed_all) {  // S:853-863 worst case: the upper bounds, normalised (spatial: twice, quirk Q3)
+        reward = -p.w_wl * (p.max_wl / p.wl_norm) - p.w_int * (p.max_int / p.int_norm);
+        wl = p.max_wl; ni = p.max_int;
+    } else {
+        double wsum; int cnt;
+        if (!ROUTES) route_centroid(p, l.hdr, l.pins, l.seg, lane, &wsum, &cnt);
+        else route_beam_or_both(p, l.hdr, l.pins, l.seg, lane, &wsum, &cnt);
+        wl = wsum / p.wl_norm;
+        ni = (double)cnt / p.int_norm;
+        reward = -1 * (p.w_wl * wl + p.w_int * ni);
+    }
+    if (lane == 0) {
+        p.buf.reward[e] = reward;
+        if (p.buf.info) { p.buf.info[2 * e] = wl; p.buf.info[2 * e + 1] = ni; }
+    }
+}
+

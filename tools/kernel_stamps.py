@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Phase profile of k_step from in-kernel s_memtime stamps (diagnostic build, never the shipped library):
 
-    hipcc ... -DPCBENV_STAMPS -o /tmp/libpcbenv_stamps.so csrc/pcbenv_kernels.hip csrc/instance_gen.cpp
-    PCBENV_STAMPS=1 PCBENV_LIB=/tmp/libpcbenv_stamps.so python tools/kernel_stamps.py [c3|c4]
+    tools/build_stamps.sh            # -DPCBENV_STAMPS build into stamps_tmp/ (travels to the GPU box)
+    PCBENV_STAMPS=1 PCBENV_LIB=$GRAFT_REPO_ROOT/stamps_tmp/libpcbenv_stamps.so python tools/kernel_stamps.py [c3|c4|c5] [envs]
 
 Prints, for one launch without and one with terminal environments (episodes in lockstep) and for one launch with
 staggered episode phases: the launch timeline from s_memrealtime (100 MHz) and the median shader cycles per phase."""

@@ -119,7 +119,7 @@ __device__ inline int cs_difference_order(CSet *A, CSet *R, int m, unsigned visi
     // points_to_visit = set(points): inserted in list order.  R doubles as the resize temporary while A is built.
     cs_init(A, 8);
     for (int i = 0; i < m; i++) cs_add(A, R, i, pt);
-    if ((m >> 2) > __popc(visited)) {
+    if ((m >> 2) > (int)__popc(visited)) {
         cs_init(R, 8);
         if (m * 5 >= R->mask * 3) { int ns = 8; while (ns <= 2 * m) ns <<= 1; cs_init(R, ns); }
         if (R->mask == A->mask) { *R = *A; }  // set_merge: same size, no dummies -> the table is copied as is

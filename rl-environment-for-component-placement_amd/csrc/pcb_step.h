@@ -36,7 +36,7 @@ __global__ __launch_bounds__(64 * NW) void k_step(DevParams p, int *__restrict__
     const bool auto_reset = p.flags & PCBENV_FLAG_AUTO_RESET;
     STAMP(1);
 
-    int o, x, y;
+    int o = 0, x = 0, y = 0;
     const int genv = (int)first_env + e;
     if (sampled) {
         const unsigned pa = l.hdr->pre_action;

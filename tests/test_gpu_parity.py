@@ -2,6 +2,8 @@
 (a) the golden episodes recorded from the reference and (b) the CPU oracle on
 device-sampled action streams.  Bit-exact: uint8 cells == reference 0/1,
 float64 features / reward / info identical bit patterns."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -515,3 +517,48 @@ def test_sampler_definition():
             env.step(torch.from_numpy(a))
             env.reset_done()
         env.close()
+
+
+@pytest.mark.parametrize("label,cfg_fn,B", [
+    ("c3_centroid", lambda: named_config("c3"), 2048),
+    ("c3_beam_k2", lambda: named_config("c3", "beam"), 1024),
+    ("c3_both_k3", lambda: EnvConfig.pin(64, 64, 9, 9, 2, 6, 2, 6, 16, 16, 8, 8, 6, 6, "both", 3, 0.5), 1024),
+    ("c4_centroid", lambda: named_config("c4"), 1024),
+    ("pin_ragged_both_k4", lambda: EnvConfig.pin(48, 40, 7, 6, 2, 6, 2, 5, 14, 8, 3, 7, 9, 2, "both", 4, 0.3), 1024),
+])
+def test_reward_sweep_many_episodes(label, cfg_fn, B):
+    """The routing reward is where rare geometry lives (shared end points, parallel segments, equal beam distances):
+    thousands of episodes per configuration, reward / done / info of every step bit-exact against the oracle replaying
+    the recorded actions.  PCBENV_SWEEP_SCALE repeats the sweep with further instance seeds."""
+    cfg = cfg_fn()
+    for rep in range(int(os.environ.get("PCBENV_SWEEP_SCALE", "1"))):
+        _reward_sweep(label, cfg, B, episodes=4, run_seed=23 + rep)
+
+
+def _reward_sweep(label, cfg, B, episodes, run_seed):
+    from oracle import oracle as orc
+    env = BatchedPlacementEnv(cfg, B, queue_depth=episodes + 1, run_seed=run_seed, auto_reset=True, incremental_obs=True)
+    packed = env.generate_instances()
+    env.reset()
+    ob = orc.OracleBatch(cfg, B)
+    ob.reset_packed(packed[0], np.ones(B, np.uint8))
+    cursor = np.ones(B, np.int64)
+    done_eps, t, n_routed = 0, 0, 0
+    while done_eps < episodes * B and t < episodes * (cfg.max_num_components + 2):
+        _, r, d, _, a = env.rollout_step(t)
+        a = a.cpu().numpy(); r = r.cpu().numpy(); d = d.cpu().numpy(); inf = env.info_raw.cpu().numpy()
+        rr, dd, ii = ob.step(a)
+        assert np.array_equal(d, dd), (label, t)
+        assert _same_bits(r, rr), (label, t, np.flatnonzero(r != rr)[:5], r[r != rr][:3], rr[r != rr][:3])
+        has = ~np.isnan(inf[:, 0])
+        assert _same_bits(inf[has], ii[has]), (label, t)
+        n_routed += int(has.sum())
+        fin = np.flatnonzero(dd)
+        if len(fin):  # the GPU has already reset these from the next queue slot
+            rec = np.stack([packed[cursor[i] % (episodes + 1)][i] for i in range(B)])
+            ob.reset_packed(rec, dd.astype(np.uint8))
+            cursor[fin] += 1
+        done_eps += int(dd.sum())
+        t += 1
+    assert done_eps >= episodes * B and n_routed >= episodes * B // 2, (done_eps, n_routed)
+    env.close()

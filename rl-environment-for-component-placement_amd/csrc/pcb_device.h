@@ -5,6 +5,8 @@
 #include <math.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "pcbenv.h"
 
 typedef unsigned long long u64;
@@ -28,6 +30,8 @@ struct DevParams {
     unsigned char *state, *queue;
     pcbenv_buffers buf;
     unsigned long long *dbg;                // diagnostic build only (-DPCBENV_STAMPS): [B][32] s_memtime stamps
+    int stream_stores;                      // observation stores bypass the caches (`nt`): see STORE16.  (Last, so that
+                                            // the kernarg offsets of the fields every wave loads first stay put.)
 };
 // In-kernel stamps (cdna_hip_programming.md §7): only in a separate diagnostic build, written to a buffer nothing
 // else reads; `PCBENV_STAMPS=1` in the environment allocates it, tools/kernel_stamps.py prints the phase profile.
@@ -129,26 +133,24 @@ template <int WW> __device__ inline Row<WW> hfold(Row<WW> r, int pw) {
     return f;
 }
 
-// 16-byte observation / state store, agent-scope write-through (`sc1`): every line written here is next read by
-// another launch (usually on another XCD) or by the policy, never by this workgroup, so leaving it dirty in the
-// XCD's L2 only defers the write to the end-of-kernel release, where the whole grid waits for it (+5 % at c3).
-// -DPCBENV_STORE_PLAIN / -DPCBENV_NT_STORES / -DPCBENV_STORE_ASM="..." keep the alternatives for A/B runs.
+// 16-byte observation store, agent-scope write-through (`sc1`): every line written here is next read by another
+// launch (usually on another XCD) or by the policy, never by this workgroup, so leaving it dirty in the XCD's L2
+// only defers the write to the end-of-kernel release, where the whole grid waits for it (+5 % at c3).
+// STREAM adds `nt`: when one launch writes well beyond the 256 MiB Infinity Cache, lines allocated there are
+// evicted before anything reads them and only cost fabric traffic (c5, 3.1 GB per launch: +10..20 %; c3 at 65 536
+// environments: 192 M -> 271 M env-steps/s), while below that size the cache absorbs the burst and streaming is the
+// slower choice (c3 / c4 at 4 096 environments: -6 %).  pcbenv_create picks by bytes per launch (DevParams).
+// -DPCBENV_STORE_PLAIN keeps plain stores for A/B runs.
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
-#define PCB_STR_(x) #x
-#define PCB_STR(x) PCB_STR_(x)
 #if defined(PCBENV_STORE_PLAIN)
-__device__ inline void STORE16(uint4 *p, uint4 v) { *p = v; }
-#elif defined(PCBENV_NT_STORES)
-__device__ inline void STORE16(uint4 *p, uint4 v) { __builtin_nontemporal_store(v4u{v.x, v.y, v.z, v.w}, (v4u *)p); }
+template <bool STREAM> __device__ inline void STORE16(uint4 *p, uint4 v) { *p = v; }
 #else
-#ifndef PCBENV_STORE_ASM
-#define PCBENV_STORE_ASM sc1
-#endif
-__device__ inline void STORE16(uint4 *p, uint4 v) {
+template <bool STREAM> __device__ inline void STORE16(uint4 *p, uint4 v) {
     v4u w{v.x, v.y, v.z, v.w};
-    // s_nop: a store wider than 64 bits may read its data VGPRs up to two wait states after issue (gfx940+ VMEM store-data
-    // hazard); the compiler pads that for its own stores but cannot see into this statement.
-    asm volatile("global_store_dwordx4 %0, %1, off " PCB_STR(PCBENV_STORE_ASM) "\n\ts_nop 1" :: "v"(p), "v"(w) : "memory");
+    // s_nop: a store wider than 64 bits may read its data VGPRs up to two wait states after issue (gfx940+ VMEM
+    // store-data hazard); the compiler pads that for its own stores but cannot see into this statement.
+    if (STREAM) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" :: "v"(p), "v"(w) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(w) : "memory");
 }
 #endif
 
@@ -160,14 +162,14 @@ __device__ inline uint4 expand16(unsigned bits) {
 
 // Write one H x W uint8 plane (0/1) from bit rows in LDS: 16 bytes per lane, 1 KiB per wave instruction.
 // Rows [r0, r1) only (full plane: 0, H).
-template <int WW> __device__ inline void emit_plane(unsigned char *dst, const u64 *bits, int r0, int r1, int W, int lane) {
+template <int WW, bool STREAM> __device__ inline void emit_plane_(unsigned char *dst, const u64 *bits, int r0, int r1, int W, int lane) {
     if ((W & 15) == 0 && (((uintptr_t)dst) & 15) == 0) {
         uint4 *d4 = (uint4 *)dst;
         const int sh = (W & (W - 1)) == 0 ? __ffs(W) - 1 : -1;
         for (int c = r0 * W / 16 + lane; c < r1 * W / 16; c += NT) {
             int cell = c * 16, r = sh >= 0 ? cell >> sh : cell / W, col = cell - r * W;
             unsigned b = (unsigned)(bits[r * WW + (col >> 6)] >> (col & 63)) & 0xFFFFu;
-            STORE16(d4 + c, expand16(b));
+            STORE16<STREAM>(d4 + c, expand16(b));
         }
     } else {  // odd widths (the reference's small test grids): byte path
         for (int i = r0 * W + lane; i < r1 * W; i += NT) {
@@ -176,13 +178,21 @@ template <int WW> __device__ inline void emit_plane(unsigned char *dst, const u6
         }
     }
 }
-__device__ inline void emit_zero(unsigned char *dst, long long bytes, int lane) {
+template <bool STREAM> __device__ inline void emit_zero_(unsigned char *dst, long long bytes, int lane) {
     if ((bytes & 15) == 0 && (((uintptr_t)dst) & 15) == 0) {
         uint4 *d4 = (uint4 *)dst;
-        for (long long c = lane; c < bytes / 16; c += NT) STORE16(d4 + c, make_uint4(0, 0, 0, 0));
+        for (long long c = lane; c < bytes / 16; c += NT) STORE16<STREAM>(d4 + c, make_uint4(0, 0, 0, 0));
     } else {
         for (long long i = lane; i < bytes; i += NT) dst[i] = 0;
     }
+}
+__device__ inline void STORE16_dyn(uint4 *p, uint4 v, bool stream) { if (stream) STORE16<true>(p, v); else STORE16<false>(p, v); }
+// the policy is chosen once per plane (wave-uniform branch), not per store
+template <int WW> __device__ inline void emit_plane(unsigned char *dst, const u64 *bits, int r0, int r1, int W, int lane, bool stream) {
+    if (stream) emit_plane_<WW, true>(dst, bits, r0, r1, W, lane); else emit_plane_<WW, false>(dst, bits, r0, r1, W, lane);
+}
+__device__ inline void emit_zero(unsigned char *dst, long long bytes, int lane, bool stream) {
+    if (stream) emit_zero_<true>(dst, bytes, lane); else emit_zero_<false>(dst, bytes, lane);
 }
 
 // Legal-placement bit mask for a ph x pw window (R:526-567, S:1792-1835):

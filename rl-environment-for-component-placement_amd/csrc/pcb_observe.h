@@ -66,11 +66,11 @@ __device__ inline bool mask_and_emit(const DevParams &p, Lds &l, int e, int lane
     const int H = p.H, W = p.W, HW = H * W, plane = H * WW;
     const int cur = l.hdr->cur;
     unsigned char *m = (emit && p.buf.action_mask) ? p.buf.action_mask + (size_t)e * p.O * HW : 0;
-    if (emit && p.buf.grid) emit_plane<WW>(p.buf.grid + (size_t)e * HW, l.occ, gr0, gr1, W, lane);
+    if (emit && p.buf.grid) emit_plane<WW>(p.buf.grid + (size_t)e * HW, l.occ, gr0, gr1, W, lane, p.stream_stores);
     bool any = false;
     if (KIND == PCBENV_SQUARE) {
         any = window_mask<WW>(l.occ, l.hf, l.vm, H, W, p.component_n, p.component_n, lane, &l.hdr->flag);
-        if (m) emit_plane<WW>(m, l.vm, 0, H, W, lane);
+        if (m) emit_plane<WW>(m, l.vm, 0, H, W, lane, p.stream_stores);
         if (emit) emit_marginals<KIND, WW>(p, l, e, lane);
         return any;
     }
@@ -78,7 +78,7 @@ __device__ inline bool mask_and_emit(const DevParams &p, Lds &l, int e, int lane
     if (cur >= 0) {
         const int h = l.comps[cur].h, w = l.comps[cur].w;
         any = window_mask<WW>(l.occ, l.hf, l.vm, H, W, h, w, lane, &l.hdr->flag);
-        if (m) { emit_plane<WW>(m, l.vm, 0, H, W, lane); if (four) emit_plane<WW>(m + 2 * HW, l.vm, 0, H, W, lane); }
+        if (m) { emit_plane<WW>(m, l.vm, 0, H, W, lane, p.stream_stores); if (four) emit_plane<WW>(m + 2 * HW, l.vm, 0, H, W, lane, p.stream_stores); }
         if (h == w) {
             for (int i = lane; i < plane; i += NT) l.vm[plane + i] = l.vm[i];
             lds_sync();
@@ -88,9 +88,9 @@ __device__ inline bool mask_and_emit(const DevParams &p, Lds &l, int e, int lane
     } else {
         for (int i = lane; i < 2 * plane; i += NT) l.vm[i] = 0ull;
         lds_sync();
-        if (m) { emit_plane<WW>(m, l.vm, 0, H, W, lane); if (four) emit_plane<WW>(m + 2 * HW, l.vm, 0, H, W, lane); }
+        if (m) { emit_plane<WW>(m, l.vm, 0, H, W, lane, p.stream_stores); if (four) emit_plane<WW>(m + 2 * HW, l.vm, 0, H, W, lane, p.stream_stores); }
     }
-    if (m) { emit_plane<WW>(m + HW, l.vm + plane, 0, H, W, lane); if (four) emit_plane<WW>(m + 3 * HW, l.vm + plane, 0, H, W, lane); }
+    if (m) { emit_plane<WW>(m + HW, l.vm + plane, 0, H, W, lane, p.stream_stores); if (four) emit_plane<WW>(m + 3 * HW, l.vm + plane, 0, H, W, lane, p.stream_stores); }
     if (emit) emit_marginals<KIND, WW>(p, l, e, lane);
     return any;
 }
@@ -118,20 +118,23 @@ template <int WW> __device__ inline void emit_pin_grid(const DevParams &p, Lds &
         // every cell owns K consecutive bytes with at most one 1 (at class-1): visit the <= 16/K + 2 cells a
         // 16-byte chunk overlaps and drop their 1-bytes into two 64-bit halves
         const unsigned kinv = 0xFFFFFFFFu / (unsigned)K + 1u;  // floor(b / K) == umulhi(b, kinv) for b < 2^32 / K
-        for (int c = (int)(b0 / 16) + lane; c < (int)(b1 / 16); c += NT) {
-            const int bb = c * 16;
-            int cell = (int)__umulhi((unsigned)bb, kinv);
-            if (cell * K > bb) cell--;  // (never taken at these sizes; keeps the division exact regardless)
-            u64 lo = 0, hi = 0;
-            for (int base = cell * K; base < bb + 16 && cell < c1; base += K, cell++) {
-                const unsigned cl = l.cls[cell];
-                const int off = base + (int)cl - 1 - bb;  // byte of this cell's 1 inside the chunk
-                if (cl != 0 && off >= 0 && off < 16) {
-                    if (off < 8) lo |= 1ull << (8 * off); else hi |= 1ull << (8 * (off - 8));
+        auto chunks = [&](auto stream_tag) {  // store policy fixed per call, not per store
+            for (int c = (int)(b0 / 16) + lane; c < (int)(b1 / 16); c += NT) {
+                const int bb = c * 16;
+                int cell = (int)__umulhi((unsigned)bb, kinv);
+                if (cell * K > bb) cell--;  // (never taken at these sizes; keeps the division exact regardless)
+                u64 lo = 0, hi = 0;
+                for (int base = cell * K; base < bb + 16 && cell < c1; base += K, cell++) {
+                    const unsigned cl = l.cls[cell];
+                    const int off = base + (int)cl - 1 - bb;  // byte of this cell's 1 inside the chunk
+                    if (cl != 0 && off >= 0 && off < 16) {
+                        if (off < 8) lo |= 1ull << (8 * off); else hi |= 1ull << (8 * (off - 8));
+                    }
                 }
+                STORE16<decltype(stream_tag)::value>(d4 + c, make_uint4((unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)));
             }
-            STORE16(d4 + c, make_uint4((unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)));
-        }
+        };
+        if (p.stream_stores) chunks(std::true_type{}); else chunks(std::false_type{});
     } else {
         for (long long i = b0 + lane; i < b1; i += NT) {
             int cell = (int)(i / K), ch = (int)(i - (long long)cell * K);

@@ -216,7 +216,7 @@ template <int KIND, int WW> __device__ inline void reset_env(const DevParams &p,
         }
         STAMP(19);
         if (KIND == PCBENV_SPATIAL) {
-            if (p.buf.pin_grid) emit_zero(p.buf.pin_grid + (size_t)e * HW * p.K, (long long)HW * p.K, lane);  // S:1504
+            if (p.buf.pin_grid) emit_zero(p.buf.pin_grid + (size_t)e * HW * p.K, (long long)HW * p.K, lane, p.stream_stores);  // S:1504
             if (p.buf.component_grid) {  // S:1677-1697 draw_components (unrotated rel coords; channel 0 == 1)
                 const int cells = p.mh * p.mw, cgsz = cells * p.K, total = p.C * cgsz;
                 unsigned char *cg = p.buf.component_grid + (size_t)e * total;
@@ -233,7 +233,7 @@ template <int KIND, int WW> __device__ inline void reset_env(const DevParams &p,
                             if (k < 8) lo |= bit << (8 * k); else hi |= bit << (8 * (k - 8));
                             if (++ch == p.K) { ch = 0; cell++; field = cell < p.C * cells ? (((u64)netmask[cell] << 1) | (u64)(cell / cells < nc)) : 0ull; }
                         }
-                        STORE16((uint4 *)cg + c16, make_uint4((unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)));
+                        STORE16_dyn((uint4 *)cg + c16, make_uint4((unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)), p.stream_stores);
                     }
                 } else {
                     for (int i = lane; i < total; i += NT) {

@@ -23,10 +23,11 @@ __device__ inline void presample_next(const DevParams &p, Lds &l, int sampled, i
     }
 }
 
-template <int KIND, int WW, int NW, bool ROUTES>
+template <int KIND, int WW, int NW, bool ROUTES, bool STREAM>
 __global__ __launch_bounds__(64 * NW) void k_step(DevParams p, int *__restrict__ actions, int fmt, int sampled,
                                                u64 seed, u64 first_env, u64 step_index) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    p.stream_stores = STREAM;  // == the launch's choice; a compile-time constant here, so only one store policy is compiled in
     const int e = blockIdx.x, lane = threadIdx.x;
     const int H = p.H, W = p.W, HW = H * W, plane = H * WW;
     STAMP_RT(30);

@@ -164,6 +164,13 @@ extern "C" int pcbenv_create(const pcbenv_config *cfg, int device, pcbenv **out)
     d.B = c.num_envs; d.Q = c.queue_depth;
     d.reward_type = c.reward_type; d.beam_width = c.reward_beam_width; d.component_n = c.component_n;
     d.flags = c.flags;
+    {   // streaming stores when one launch writes well beyond the 256 MiB Infinity Cache (see STORE16)
+        const long long cells = (long long)c.height * c.width;
+        const long long per_env = (c.flags & PCBENV_FLAG_INCREMENTAL_OBS) ? cells * d.O : cells * (1 + d.O + (c.kind == PCBENV_SPATIAL ? d.K : 0));
+        long long threshold_mb = 384;
+        if (const char *ev = getenv("PCBENV_STREAM_THRESHOLD_MB")) threshold_mb = atoll(ev);
+        d.stream_stores = per_env * c.num_envs > threshold_mb * (1ll << 20);
+    }
     d.w_wl = c.weight_wirelength; d.w_int = c.weight_num_intersections;
     d.area = (double)(c.height * c.width);
     if (is_pin_kind(c.kind)) {  // a15 (S:724-791, P:757-830) and the normalisers of find_reward (S:839-850)
@@ -292,7 +299,8 @@ template <int KIND> static int launch_reset(pcbenv *env, const uint8_t *mask, hi
 template <int KIND> static int launch_step(pcbenv *env, int *actions, int fmt, int sampled, u64 seed, u64 first_env,
                                            u64 step_index, hipStream_t s) {
     const DevParams &d = env->dp;
-#define LAUNCH_STEP(WW_, NW_, RT_) hipLaunchKernelGGL((k_step<KIND, WW_, NW_, RT_>), dim3(d.B), dim3(64 * NW_), d.ldsBytes, s, d, actions, fmt, sampled, seed, first_env, step_index)
+#define LAUNCH_STEP_(WW_, NW_, RT_, ST_) hipLaunchKernelGGL((k_step<KIND, WW_, NW_, RT_, ST_>), dim3(d.B), dim3(64 * NW_), d.ldsBytes, s, d, actions, fmt, sampled, seed, first_env, step_index)
+#define LAUNCH_STEP(WW_, NW_, RT_) do { if (d.stream_stores) LAUNCH_STEP_(WW_, NW_, RT_, true); else LAUNCH_STEP_(WW_, NW_, RT_, false); } while (0)
     constexpr bool PINK = (KIND == PCBENV_PIN || KIND == PCBENV_SPATIAL);
     const bool routes = PINK && env->cfg.reward_type != PCBENV_REWARD_CENTROID;
     if (routes) {

@@ -167,7 +167,7 @@ extern "C" int pcbenv_create(const pcbenv_config *cfg, int device, pcbenv **out)
     {   // streaming stores when one launch writes well beyond the 256 MiB Infinity Cache (see STORE16)
         const long long cells = (long long)c.height * c.width;
         const long long per_env = (c.flags & PCBENV_FLAG_INCREMENTAL_OBS) ? cells * d.O : cells * (1 + d.O + (c.kind == PCBENV_SPATIAL ? d.K : 0));
-        long long threshold_mb = 384;
+        long long threshold_mb = 256;
         if (const char *ev = getenv("PCBENV_STREAM_THRESHOLD_MB")) threshold_mb = atoll(ev);
         d.stream_stores = per_env * c.num_envs > threshold_mb * (1ll << 20);
     }

@@ -257,15 +257,19 @@ __device__ inline void route_beam_or_both(const DevParams &p, const EnvHdr *hdr,
     const SegView v = seg_view(seg, p.P);
     unsigned char *beam = v.beam;
     net_offsets_and_centroids(v, hdr, pins, lane);
+    STAMP(5);
     for (int n = lane; n < hdr->nnets; n += NT)
         beam_route_net(v, pins, v.nstart[n], v.nstart[n + 1] - v.nstart[n], p.beam_width, beam + (size_t)n * BEAM_LDS_PER_NET(p.beam_width));
     lds_sync();
+    STAMP(24);
     count_and_length(p, v, hdr, pins, lane, wirelength, nintersections);
+    STAMP(25);
     if (p.reward_type == PCBENV_REWARD_BOTH) {  // S:609-627 lowest_num_intersections: ties keep the beam route
         double wc; int kc;
         build_centroid_segments(v, hdr, pins, lane);
         count_and_length(p, v, hdr, pins, lane, &wc, &kc);
         if (kc < *nintersections) { *nintersections = kc; *wirelength = wc; }
     }
+    STAMP(8);
 }
 

@@ -18,11 +18,12 @@ from pcbenv import named_config  # noqa: E402
 from pcbenv.batched_env import BatchedPlacementEnv  # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else "c3"
-cfg = named_config(name)
+reward = sys.argv[3] if len(sys.argv) > 3 else "centroid"
+cfg = named_config(name, reward)
 B, L = int(sys.argv[2]) if len(sys.argv) > 2 else 4096, cfg.max_num_components
 TERM = [("load", 0, 1), ("sample", 1, 2), ("update", 2, 3), ("fold+emit", 3, 4), ("reward:offsets+centroids", 4, 5),
-        ("reward:segments", 5, 6), ("reward:terms+prefix", 6, 22), ("reward:pair walk", 12, 13), ("reward:tail batch", 13, 14),
-        ("reward:reduce", 14, 15), ("reward:wirelength", 15, 8), ("reset:instance+Q1", 9, 16), ("reset:fold+emit", 16, 17),
+        ("reward:segments (centroid) / beam search", 5, 6 if reward == "centroid" else 24), ("beam: count", 24, 25), ("both: centroid route + count", 25, 8), ("reward:terms+prefix", 6, 22), ("reward:pair walk", 12, 13), ("reward:tail batch", 13, 14),
+        ("reward:reduce", 14, 15), ("reward:wirelength", 15, 8 if reward == "centroid" else 15), ("reset:instance+Q1", 9, 16), ("reset:fold+emit", 16, 17),
         ("reset:component features", 17, 18), ("reset:pin features", 18, 19), ("reset:rest", 19, 10), ("presample", 10, 20),
         ("store state", 20, 11)]
 NONT = [("load", 0, 1), ("sample", 1, 2), ("update", 2, 3), ("fold+emit grid/mask", 3, 23), ("emit pin_grid", 23, 4), ("rest", 4, 10), ("presample", 10, 20),

@@ -519,6 +519,47 @@ def test_sampler_definition():
         env.close()
 
 
+def test_presampled_action_is_never_stale():
+    """The fused sampler draws the action of step t+1 at the end of the launch of step t and keeps it in the state
+    header; whatever happens in between -- jumps in the step index, another seed, an explicit step, a masked reset,
+    restoring an older state -- the action a fused launch takes must equal what pcbenv_sample_actions draws from the
+    mask the launch starts from."""
+    for name in ("c2", "c3", "c4"):
+        cfg = named_config(name)
+        B = 64
+        env = BatchedPlacementEnv(cfg, B, queue_depth=2, run_seed=9, auto_reset=True)
+        env.generate_instances(); env.reset()
+        rng = np.random.RandomState(1)
+
+        def fused(t):
+            want = env.sample_actions(t).clone()
+            _, _, _, _, got = env.rollout_step(t)
+            assert torch.equal(got, want), (name, t)
+
+        t = 0
+        for _ in range(3):
+            fused(t); t += 1                       # consecutive: the presampled action is used
+        fused(t + 5); t += 6                       # step index jumps: tag mismatch -> fresh draw
+        fused(t); t += 1
+        env.run_seed += 1                          # another seed
+        fused(t); t += 1
+        fused(t); t += 1
+        a = env.sample_actions(1234)               # explicit step in between clears the presampled action
+        env.step(a)
+        fused(t); t += 1
+        fused(t); t += 1
+        snap = env.state_dict()
+        fused(t); fused(t + 1)
+        env.load_state_dict(snap)                  # older state, with the action presampled for step t
+        fused(t); t += 1
+        mask = torch.from_numpy((rng.rand(B) < 0.5).astype(np.uint8)).to(env.device)
+        env.reset(mask)                            # masked reset changes the mask under a presampled action
+        fused(t); t += 1
+        for _ in range(cfg.max_num_components + 2):  # across the in-launch resets
+            fused(t); t += 1
+        env.close()
+
+
 @pytest.mark.parametrize("label,cfg_fn,B", [
     ("c3_centroid", lambda: named_config("c3"), 2048),
     ("c3_beam_k2", lambda: named_config("c3", "beam"), 1024),

@@ -173,7 +173,10 @@ int pcbenv_sample_actions(pcbenv *env, int32_t *actions_dev, int32_t action_form
                           uint64_t first_env_index, uint64_t step_index, void *stream);
 
 /* pcbenv_sample_actions + pcbenv_step in one launch: draws the action exactly as pcbenv_sample_actions would,
- * stores it in actions_out_dev (the trajectory record) and applies it. */
+ * stores it in actions_out_dev (the trajectory record) and applies it.  (The launch also draws, for the same seed and
+ * step_index + 1, the action of the next call and keeps it in the state block; it is used only if the next call asks
+ * for exactly that (seed, step, environment) and the mask has not changed since -- the result is the same function
+ * of (mask, seed, environment, step) either way.) */
 int pcbenv_step_sampled(pcbenv *env, int32_t *actions_out_dev, int32_t action_format, uint64_t seed,
                         uint64_t first_env_index, uint64_t step_index, void *stream);
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Observation-level soak: every observation tensor, reward, done and info of every environment at every step against
 the CPU oracle, at large batches, in the explicit / fused auto-reset / incremental modes (test infrastructure: this
-drives tests/test_gpu_parity.py:_oracle_rollout).  tools/soak_obs.py [scale]"""
+drives test_gpu_parity.py:_oracle_rollout; it lives under tests/ because it uses the oracle).  python tests/soak_obs.py [scale]"""
 import os
 import sys
 import time

@@ -287,7 +287,9 @@ def main():
                 "config": {"workload": f"{args.config}: {cfg.height}x{cfg.width} grid, {cfg.max_num_components} components, "
                                        f"{cfg.max_total_pins} pins, reward={args.reward}", "envs_per_gpu": B,
                            "queue_depth": args.queue_depth, "incremental_obs": bool(args.incremental), "loop": args.loop, "steps_per_host_call": chunk,
-                           "instance_generation_s": round(t_gen, 2)},
+                           "instance_generation_s": round(t_gen, 2),
+                           "store_policy": "sc1 nt (streaming)" if cfg.cell_tensor_bytes_per_step(args.incremental) * B
+                           > int(os.environ.get("PCBENV_STREAM_THRESHOLD_MB", "256")) * (1 << 20) else "sc1 (write-through)"},
                 "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(line), flush=True)
     env.close()

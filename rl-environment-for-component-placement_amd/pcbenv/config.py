@@ -121,6 +121,13 @@ class EnvConfig:
         return min(self.max_num_pins_per_net * self.max_num_nets,
                    self.max_num_components * self.max_num_pins_per_component)
 
+    def cell_tensor_bytes_per_step(self, incremental: bool = False) -> int:
+        """uint8 cell tensors one environment rewrites per step (grid, action_mask, pin_grid): what pcbenv_create
+        compares with the Infinity Cache size to choose the store policy."""
+        planes = self.num_orientations if incremental else 1 + self.num_orientations + (
+            self.max_num_nets + 1 if self.kind == KIND_SPATIAL else 0)
+        return self.area * planes
+
     @property
     def reward_type_code(self) -> int:
         return REWARD_TYPES.get(self.reward_type, -1)

@@ -519,6 +519,53 @@ def test_sampler_definition():
         env.close()
 
 
+def test_step_is_graph_capturable_with_a_policy():
+    """pcbenv_step enqueues kernels on the caller's stream and nothing else (no allocation, copy or synchronisation), so
+    a policy forward + step can be captured once in a HIP graph (torch.cuda.CUDAGraph) and replayed: the replays
+    must produce what the eager loop produces, across the in-launch resets."""
+    cfg = named_config("c4")
+    B = 256
+
+    def make():
+        env = BatchedPlacementEnv(cfg, B, queue_depth=2, auto_reset=True, run_seed=1)
+        env.generate_instances(); env.reset()
+        return env
+
+    torch.manual_seed(0)
+    pol = torch.nn.Conv2d(1, 4, 3, padding=1).cuda()
+    HW = cfg.height * cfg.width
+
+    def policy_step(env, out):
+        with torch.no_grad():
+            logits = pol(env.obs["grid"].float().unsqueeze(1)).flatten(1)        # [B, 4*H*W], (o, x, y) order
+            flat = logits.masked_fill(~env.obs["action_mask"].flatten(1).bool(), -1e9).argmax(dim=1)
+            out[:, 0] = (flat // HW).int(); out[:, 1] = ((flat % HW) // cfg.width).int(); out[:, 2] = (flat % cfg.width).int()
+        env.step(out)
+
+    a, w = make(), make()
+    acts_a = torch.empty((B, 3), dtype=torch.int32, device="cuda")
+    acts_b = torch.empty((B, 3), dtype=torch.int32, device="cuda")
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):  # warm-up off the default stream, as torch asks for before a capture
+        for _ in range(3):
+            policy_step(w, acts_b)
+    torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
+    w.close()
+    b = make()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        policy_step(b, acts_b)
+    for t in range(cfg.max_num_components + 4):
+        policy_step(a, acts_a)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(acts_a, acts_b), t
+        assert torch.equal(a.reward, b.reward) and torch.equal(a.done, b.done), t
+        for k in a.obs:
+            assert torch.equal(a.obs[k], b.obs[k]), (t, k)
+    a.close(); b.close()
+
+
 def test_presampled_action_is_never_stale():
     """The fused sampler draws the action of step t+1 at the end of the launch of step t and keeps it in the state
     header; whatever happens in between -- jumps in the step index, another seed, an explicit step, a masked reset,

@@ -151,17 +151,42 @@ def main():
     ap.add_argument("--event-steps", type=int, default=128, help="extra steps timed per kernel launch with HIP events")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the multi-rank path on one GPU)")
     ap.add_argument("--device-index", type=int, default=-1, help="GPU index of this rank (default LOCAL_RANK)")
-    ap.add_argument("--adv-allgather", action="store_true", help="N > 1: every 16 steps all-gather + standardise a [16*B] float32 advantage tensor (the PPO-side collective)")
+    ap.add_argument("--adv-allgather", dest="adv_allgather", action="store_true", default=None,
+                    help="N > 1 (default there): every 16 steps all-gather + standardise a [16*B] float32 advantage tensor "
+                         "(the PPO-side collective, 256 KiB per rank at 4 096 envs) over RCCL")
+    ap.add_argument("--no-adv-allgather", dest="adv_allgather", action="store_false")
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; `value` comes from the first, the spread of all is reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start N fresh ranks (one per GPU) and relay rank 0's line.
+        # Nothing in this process has touched the GPU (importing torch does not), and it is not replaced: the ranks
+        # are children, their stdout is ours.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd).returncode)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    if args.adv_allgather is None:
+        args.adv_allgather = world > 1
     dev_index = local_rank if args.device_index < 0 else args.device_index
+    if args.backend != "nccl" and args.device_index < 0:
+        dev_index = local_rank % torch.cuda.device_count()  # rehearsal: more ranks than GPUs share the cards
     torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
@@ -174,7 +199,8 @@ def main():
     from pcbenv import named_config
     from pcbenv.batched_env import BatchedPlacementEnv
     cfg = named_config(args.config, args.reward)
-    B = args.envs or {"c1": 1, "c2": 1024, "c3": 4096, "c4": 4096, "c5": 8192}[args.config]
+    default_B = {"c1": 1, "c2": 1024, "c3": 4096, "c4": 4096, "c5": 8192}[args.config]
+    B = args.envs or default_B
     env = BatchedPlacementEnv(cfg, B, device=f"cuda:{dev_index}", queue_depth=args.queue_depth,
                               run_seed=args.run_seed, first_env_index=rank * B, incremental_obs=args.incremental,
                               auto_reset=(args.loop == "fused"), threads_per_env=args.threads_per_env)
@@ -206,41 +232,59 @@ def main():
     # step IS one k_step launch, so one event pair around the timed region gives the mean launch duration with
     # no per-launch event overhead; in the explicit loop a pair brackets each k_step launch (this costs ~5 us
     # per event and is therefore done in a second, untimed-for-`value` pass).
-    ev_region = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
     chunk = max(1, args.chunk) if args.loop == "fused" else 1
     chunk_actions = torch.empty((chunk, B, 3), dtype=torch.int32, device=env.device) if chunk > 1 else None
-    t0 = time.perf_counter()
-    ev_region[0].record()
-    if chunk > 1:
-        for k in range(0, args.steps, chunk):
-            env.rollout_steps(args.warmup + k, min(chunk, args.steps - k), out=chunk_actions)
-    else:
-        adv = torch.randn(16 * B, device=env.device) if (dist and args.adv_allgather) else None
-        for k in range(args.steps):
-            one_step(args.warmup + k)
-            if adv is not None and k % 16 == 15:
-                from pcbenv.distributed import normalize_advantages
-                adv_n = normalize_advantages(adv if args.backend == "nccl" else adv.cpu(), "all_gather")  # noqa: F841
-    ev_region[1].record()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=env.device if args.backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    adv = torch.randn(16 * B, device=env.device) if (dist and args.adv_allgather) else None
+    if adv is not None:
+        from pcbenv.distributed import normalize_advantages
+
+    def timed_region(step0):
+        """EXACTLY args.steps steps between barrier + synchronize on both sides -> (own wall seconds, event ms)."""
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        t0 = time.perf_counter()
+        ev[0].record()
+        if chunk > 1:
+            for k in range(0, args.steps, chunk):
+                env.rollout_steps(step0 + k, min(chunk, args.steps - k), out=chunk_actions)
+        else:
+            for k in range(args.steps):
+                one_step(step0 + k)
+                if adv is not None and k % 16 == 15:  # the PPO-side collective: 64 KiB * B / 1024 per rank over RCCL
+                    normalize_advantages(adv if args.backend == "nccl" else adv.cpu(), "all_gather")
+        ev[1].record()
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        return time.perf_counter() - t0, ev[0].elapsed_time(ev[1])
+
+    def over_ranks(x):
+        """-> (max over ranks, list of per-rank values)"""
+        if not dist:
+            return x, [x]
+        tt = torch.tensor([x], dtype=torch.float64, device=env.device if args.backend == "nccl" else "cpu")
+        allv = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(allv, tt)
+        vals = [float(v.item()) for v in allv]
+        return max(vals), vals
+
+    own, region_ms = timed_region(args.warmup)
+    elapsed, per_rank_s = over_ranks(own)
+    repeats_ms = [elapsed / args.steps * 1e3]
+    for r in range(1, max(1, args.repeats)):  # the spread: further regions of the same length, not part of `value`
+        own_r, _ = timed_region(args.warmup + r * args.steps)
+        repeats_ms.append(over_ranks(own_r)[0] / args.steps * 1e3)
+    steps_done = args.warmup + max(1, args.repeats) * args.steps
     step_kernel_ms = None
     if not args.no_kernel_events:
         if args.loop == "fused" and cfg.reward_type == "centroid":
-            step_kernel_ms = ev_region[0].elapsed_time(ev_region[1]) / args.steps
+            step_kernel_ms = region_ms / args.steps
         elif args.event_steps > 0:
             events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.event_steps)]
             for k in range(args.event_steps):
-                one_step(args.warmup + args.steps + k, events[k])
+                one_step(steps_done + k, events[k])
             torch.cuda.synchronize()
             step_kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
 
@@ -257,15 +301,19 @@ def main():
         roof = None
         if step_kernel_ms:
             achieved = b_alg * B / (step_kernel_ms * 1e-3) / 1e9
-            traffic = None
-            tpath = os.path.join(REPO, "profiles", f"traffic_{args.config}.json")
-            if os.path.exists(tpath):
+            # HBM bytes per launch from the PMC counters: collected in separate rocprofv3 --pmc passes of this same
+            # command (tools/profile_all.sh) and committed; a bench run cannot read the counters itself.
+            traffic, traffic_source = None, None
+            tname = f"traffic_{args.config}.json" if B == default_B else f"traffic_{args.config}_{B}.json"
+            tpath = os.path.join(REPO, "profiles", tname)
+            if os.path.exists(tpath) and not args.incremental and args.loop == "fused":
                 try:
                     traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                    traffic_source = "profiles/" + tname + " (rocprofv3 --pmc passes of this command, not this run)"
                 except Exception:
                     traffic = None
             roof = {"bound": "hbm", "kernel": "k_step", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                    "frac": round(achieved / 8000.0, 4), "traffic": traffic,
+                    "frac": round(achieved / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_source,
                     "measured_copy_ceiling": round(measured_copy_ceiling_gbps(env.device), 1),
                     "measured_fill_ceiling": round(measured_fill_ceiling_gbps(env.device), 1),
                     "algorithmic_bytes_per_env_step": b_alg, "units_per_launch": B,
@@ -282,6 +330,12 @@ def main():
                    "cpu_model": host_cpu_model(), "host_logical_cpus": os.cpu_count()}
         line = {"metric": "env_steps_per_sec", "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+                "ms_per_step_repeats": {"n": len(repeats_ms), "median": round(float(np.median(repeats_ms)), 5),
+                                        "min": round(min(repeats_ms), 5), "max": round(max(repeats_ms), 5)},
+                "per_rank_env_steps_per_sec": [round(B * args.steps / t, 1) for t in per_rank_s],
+                "world_size_observed": (dist.get_world_size() if dist else 1),
+                "backend": (("rccl" if args.backend == "nccl" else args.backend) if dist else None),
+                "adv_allgather_bytes_per_rank": (16 * B * 4 if adv is not None else 0),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
                 "data": "synthetic (reference-exact instance generator, seeds 1000003*run_seed+env; uniform legal actions drawn on device)",
                 "config": {"workload": f"{args.config}: {cfg.height}x{cfg.width} grid, {cfg.max_num_components} components, "

@@ -88,6 +88,8 @@ def lib():
         L.orc_batch_env.argtypes = [C.c_void_p, C.c_int]
         L.orc_batch_reset_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int]
         L.orc_batch_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_batch_first_mismatch.restype = C.c_int64
+        L.orc_batch_first_mismatch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int]
         _lib = L
     return _lib
 
@@ -235,6 +237,17 @@ class OracleBatch:
                                             None if m is None else m.ctypes.data, threads)
         if rc != 0:
             raise RuntimeError("orc_batch_reset_packed failed")
+
+    def first_mismatch(self, key: str, dev_copy: np.ndarray, threads: int = 1) -> int:
+        """First environment whose observation `key` differs from `dev_copy` (host copy of the device tensor, uint8
+        cells or float64 features, leading dim = environments); -1 if the whole batch agrees."""
+        a = np.ascontiguousarray(dev_copy)
+        assert a.shape[0] == self.n and a.dtype in (np.uint8, np.float64), (a.shape, a.dtype)
+        rc = self._L.orc_batch_first_mismatch(self._h, _OBS[key], a.ctypes.data, a.dtype.itemsize,
+                                              int(a.size // self.n), threads)
+        if rc == -2:
+            raise ValueError(f"{key}: element count per environment differs from the oracle's")
+        return int(rc)
 
     def step(self, actions: np.ndarray, threads: int = 1):
         a = np.ascontiguousarray(actions, np.int32).reshape(self.n, 3)

@@ -75,3 +75,32 @@ int orc_batch_step(orc_batch *b, const int32_t *actions, double *reward, uint8_t
     }
     return err ? -1 : 0;
 }
+
+/* Whole-batch observation check (tests): compares observation `key` of every environment with a host copy of the
+ * device tensor -- uint8 cells (elem_bytes 1: value == the oracle's float64 0.0/1.0) or float64 features
+ * (elem_bytes 8: identical bit patterns).  Returns the first environment that differs, -1 if none, -2 if the
+ * element count per environment is not the oracle's. */
+const double *orc_obs(const orc_env *e, int key, int64_t *count);
+int64_t orc_batch_first_mismatch(orc_batch *b, int key, const void *dev_copy, int elem_bytes, int64_t per_env,
+                                 int threads) {
+    int64_t first = -1;
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (int i = 0; i < b->n; i++) {
+        int64_t cnt = 0;
+        const double *ref = orc_obs(b->envs[i], key, &cnt);
+        int64_t bad = -1;
+        if (cnt != per_env) bad = -2;
+        else if (elem_bytes == 1) {
+            const uint8_t *g = (const uint8_t *)dev_copy + (size_t)i * (size_t)per_env;
+            for (int64_t k = 0; k < cnt; k++) if ((double)g[k] != ref[k]) { bad = i; break; }
+        } else {
+            const double *g = (const double *)dev_copy + (size_t)i * (size_t)per_env;
+            if (memcmp(g, ref, (size_t)cnt * 8) != 0) bad = i;
+        }
+        if (bad != -1) {
+#pragma omp critical
+            { if (first == -1 || bad == -2 || (first >= 0 && bad >= 0 && bad < first)) first = bad; }
+        }
+    }
+    return first;
+}

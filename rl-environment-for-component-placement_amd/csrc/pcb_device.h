@@ -140,17 +140,26 @@ template <int WW> __device__ inline Row<WW> hfold(Row<WW> r, int pw) {
 // evicted before anything reads them and only cost fabric traffic (c5, 3.1 GB per launch: +10..20 %; c3 at 65 536
 // environments: 192 M -> 271 M env-steps/s), while below that size the cache absorbs the burst and streaming is the
 // slower choice (c3 / c4 at 4 096 environments: -6 %).  pcbenv_create picks by bytes per launch (DevParams).
-// -DPCBENV_STORE_PLAIN keeps plain stores for A/B runs.
+// The stores are raw buffer stores (buffer_store_dwordx4 ... sc1 [nt]) through a per-environment resource
+// descriptor: the cache policy travels in the builtin's aux operand, so the compiler schedules them (and their
+// gfx950 store-data wait states) itself, and the descriptor's byte count makes an out-of-range chunk a dropped
+// store instead of a fault.  -DPCBENV_STORE_PLAIN keeps plain global stores for A/B runs.
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 #if defined(PCBENV_STORE_PLAIN)
-template <bool STREAM> __device__ inline void STORE16(uint4 *p, uint4 v) { *p = v; }
+struct ObsDst { unsigned char *base; };
+__device__ inline ObsDst obs_dst(unsigned char *base, long long) { return ObsDst{base}; }
+template <bool STREAM> __device__ inline void STORE16(const ObsDst &d, unsigned off, uint4 v) { *(uint4 *)(d.base + off) = v; }
 #else
-template <bool STREAM> __device__ inline void STORE16(uint4 *p, uint4 v) {
-    v4u w{v.x, v.y, v.z, v.w};
-    // s_nop: a store wider than 64 bits may read its data VGPRs up to two wait states after issue (gfx940+ VMEM
-    // store-data hazard); the compiler pads that for its own stores but cannot see into this statement.
-    if (STREAM) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" :: "v"(p), "v"(w) : "memory");
-    else asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(w) : "memory");
+struct ObsDst { __amdgpu_buffer_rsrc_t rsrc; };
+// base must be wave-uniform (it is: tensor pointer + blockIdx.x * per-environment bytes)
+__device__ inline ObsDst obs_dst(unsigned char *base, long long bytes) {
+    return ObsDst{__builtin_amdgcn_make_buffer_rsrc(base, 0, (int)bytes, 0x00020000)};
+}
+#define PCBENV_AUX_SC1 16
+#define PCBENV_AUX_NT 2
+template <bool STREAM> __device__ inline void STORE16(const ObsDst &d, unsigned off, uint4 v) {
+    const v4u w{v.x, v.y, v.z, v.w};
+    __builtin_amdgcn_raw_buffer_store_b128(w, d.rsrc, (int)off, 0, STREAM ? (PCBENV_AUX_SC1 | PCBENV_AUX_NT) : PCBENV_AUX_SC1);
 }
 #endif
 
@@ -164,12 +173,12 @@ __device__ inline uint4 expand16(unsigned bits) {
 // Rows [r0, r1) only (full plane: 0, H).
 template <int WW, bool STREAM> __device__ inline void emit_plane_(unsigned char *dst, const u64 *bits, int r0, int r1, int W, int lane) {
     if ((W & 15) == 0 && (((uintptr_t)dst) & 15) == 0) {
-        uint4 *d4 = (uint4 *)dst;
+        const ObsDst d = obs_dst(dst, (long long)r1 * W);
         const int sh = (W & (W - 1)) == 0 ? __ffs(W) - 1 : -1;
         for (int c = r0 * W / 16 + lane; c < r1 * W / 16; c += NT) {
             int cell = c * 16, r = sh >= 0 ? cell >> sh : cell / W, col = cell - r * W;
             unsigned b = (unsigned)(bits[r * WW + (col >> 6)] >> (col & 63)) & 0xFFFFu;
-            STORE16<STREAM>(d4 + c, expand16(b));
+            STORE16<STREAM>(d, (unsigned)cell, expand16(b));
         }
     } else {  // odd widths (the reference's small test grids): byte path
         for (int i = r0 * W + lane; i < r1 * W; i += NT) {
@@ -180,13 +189,13 @@ template <int WW, bool STREAM> __device__ inline void emit_plane_(unsigned char 
 }
 template <bool STREAM> __device__ inline void emit_zero_(unsigned char *dst, long long bytes, int lane) {
     if ((bytes & 15) == 0 && (((uintptr_t)dst) & 15) == 0) {
-        uint4 *d4 = (uint4 *)dst;
-        for (long long c = lane; c < bytes / 16; c += NT) STORE16<STREAM>(d4 + c, make_uint4(0, 0, 0, 0));
+        const ObsDst d = obs_dst(dst, bytes);
+        for (int c = lane; c < (int)(bytes / 16); c += NT) STORE16<STREAM>(d, (unsigned)c * 16u, make_uint4(0, 0, 0, 0));
     } else {
         for (long long i = lane; i < bytes; i += NT) dst[i] = 0;
     }
 }
-__device__ inline void STORE16_dyn(uint4 *p, uint4 v, bool stream) { if (stream) STORE16<true>(p, v); else STORE16<false>(p, v); }
+__device__ inline void STORE16_dyn(const ObsDst &d, unsigned off, uint4 v, bool stream) { if (stream) STORE16<true>(d, off, v); else STORE16<false>(d, off, v); }
 // the policy is chosen once per plane (wave-uniform branch), not per store
 template <int WW> __device__ inline void emit_plane(unsigned char *dst, const u64 *bits, int r0, int r1, int W, int lane, bool stream) {
     if (stream) emit_plane_<WW, true>(dst, bits, r0, r1, W, lane); else emit_plane_<WW, false>(dst, bits, r0, r1, W, lane);

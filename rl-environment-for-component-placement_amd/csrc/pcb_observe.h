@@ -114,7 +114,7 @@ template <int WW> __device__ inline void emit_pin_grid(const DevParams &p, Lds &
     }
     lds_sync();
     if ((b0 & 15) == 0 && (b1 & 15) == 0 && (((uintptr_t)dst) & 15) == 0) {
-        uint4 *d4 = (uint4 *)dst;
+        const ObsDst d = obs_dst(dst, b1);
         // every cell owns K consecutive bytes with at most one 1 (at class-1): visit the <= 16/K + 2 cells a
         // 16-byte chunk overlaps and drop their 1-bytes into two 64-bit halves
         const unsigned kinv = 0xFFFFFFFFu / (unsigned)K + 1u;  // floor(b / K) == umulhi(b, kinv) for b < 2^32 / K
@@ -131,7 +131,7 @@ template <int WW> __device__ inline void emit_pin_grid(const DevParams &p, Lds &
                         if (off < 8) lo |= 1ull << (8 * off); else hi |= 1ull << (8 * (off - 8));
                     }
                 }
-                STORE16<decltype(stream_tag)::value>(d4 + c, make_uint4((unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)));
+                STORE16<decltype(stream_tag)::value>(d, (unsigned)bb, make_uint4((unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)));
             }
         };
         if (p.stream_stores) chunks(std::true_type{}); else chunks(std::false_type{});

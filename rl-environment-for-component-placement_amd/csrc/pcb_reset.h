@@ -222,6 +222,7 @@ template <int KIND, int WW> __device__ inline void reset_env(const DevParams &p,
                 unsigned char *cg = p.buf.component_grid + (size_t)e * total;
                 // byte (cell, ch) = ch == 0 ? component exists : net ch-1 has a pin on the cell; each byte written once
                 if ((total & 15) == 0 && (((uintptr_t)cg) & 15) == 0) {
+                    const ObsDst d = obs_dst(cg, total);
                     for (int c16 = lane; c16 < total / 16; c16 += NT) {
                         const int bb = c16 * 16;
                         int cell = bb / p.K, ch = bb - cell * p.K;
@@ -233,7 +234,7 @@ template <int KIND, int WW> __device__ inline void reset_env(const DevParams &p,
                             if (k < 8) lo |= bit << (8 * k); else hi |= bit << (8 * (k - 8));
                             if (++ch == p.K) { ch = 0; cell++; field = cell < p.C * cells ? (((u64)netmask[cell] << 1) | (u64)(cell / cells < nc)) : 0ull; }
                         }
-                        STORE16_dyn((uint4 *)cg + c16, make_uint4((unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)), p.stream_stores);
+                        STORE16_dyn(d, (unsigned)bb, make_uint4((unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)), p.stream_stores);
                     }
                 } else {
                     for (int i = lane; i < total; i += NT) {

@@ -80,6 +80,7 @@ __global__ __launch_bounds__(64 * NW) void k_step(DevParams p, int *__restrict__
         if (KIND == PCBENV_SQUARE || KIND == PCBENV_RECT) { if (lane == 0) p.buf.reward[e] = 0.0; }
         else terminal_reward<KIND, ROUTES>(p, l, e, lane);
         if (auto_reset) {
+            __syncthreads();  // as below: the reset rewrites addresses this launch may still be storing to
             reset_env<KIND, WW>(p, l, e, lane);
             presample_next(p, l, sampled, genv, seed, step_index + 1, lane);
             store_state(smem, p, e, lane);
@@ -149,7 +150,15 @@ __global__ __launch_bounds__(64 * NW) void k_step(DevParams p, int *__restrict__
     else if (!done) { if (lane == 0) p.buf.reward[e] = 0.0; }
     else terminal_reward<KIND, ROUTES>(p, l, e, lane);
     STAMP(9);
-    if (done && auto_reset) reset_env<KIND, WW>(p, l, e, lane);  // rewrites every observation
+    if (done && auto_reset) {
+        // The reset rewrites every observation, some of them bytes this launch has just stored from other lanes
+        // and (four-wavefront environments) other wavefronts: feature rows of the placed component, and -- when the
+        // episode ended with no legal cell left, so that nothing was skipped above -- grid / pin_grid / mask chunks.
+        // lds_sync() orders LDS only, so drain the stores (s_waitcnt vmcnt(0)) and meet before overwriting them.
+        // Terminal wavefronts are latency-bound on the reward; the drain is free by the time they get here.
+        __syncthreads();
+        reset_env<KIND, WW>(p, l, e, lane);
+    }
     STAMP(10);
     presample_next(p, l, sampled, genv, seed, step_index + 1, lane);
     STAMP(20);

@@ -257,19 +257,31 @@ extern "C" int pcbenv_load_instances(pcbenv *env, const int32_t *env_ids, int32_
     const long long src_stride = pcbenv_instance_stride(&env->cfg);
     hipStream_t s = (hipStream_t)stream;
     const unsigned char *src = (const unsigned char *)host_tables;
-    // sanity-check the records (bad tables would index out of bounds on the device)
+    // sanity-check the records: every index the kernels derive from a record (component, net, feature row, cell
+    // inside the component) must stay inside the tables and LDS zones sized from the configuration
+    const bool pin_kind = is_pin_kind(env->cfg.kind), spatial = env->cfg.kind == PCBENV_SPATIAL;
     for (int i = 0; i < n; i++) {
         const int32_t *h = (const int32_t *)(src + (size_t)i * src_stride);
-        if (h[0] < 1 || h[0] > d.C || h[2] < 0 || h[2] > d.P || h[1] < 0 || h[1] > PCBENV_MAX_NETS)
-            return fail(env, PCBENV_EINVAL, "instance record out of range");
+        if (h[0] < 1 || h[0] > d.C || h[2] < 0 || h[2] > d.P || h[1] < 0 || h[1] > d.N)
+            return fail(env, PCBENV_EINVAL, "instance record out of range (components, nets or pins beyond the configuration)");
+        if (!pin_kind && (h[1] != 0 || h[2] != 0)) return fail(env, PCBENV_EINVAL, "instance record carries pins for an environment kind without pins");
         const unsigned char *cr = (const unsigned char *)h + 16, *pr = cr + 8 * (size_t)d.C;
         for (int c = 0; c < h[0]; c++)
             if (cr[8 * c] < 1 || cr[8 * c] > d.mh || cr[8 * c + 1] < 1 || cr[8 * c + 1] > d.mw) return fail(env, PCBENV_EINVAL, "component size out of range");
         int prev = 0;
+        unsigned char seen[(PCBENV_MAX_PINS + 7) / 8] = {0};
+        int per_net[PCBENV_MAX_NETS] = {0};
         for (int q = 0; q < h[2]; q++) {
-            int net = pr[8 * q + 2], comp = pr[8 * q + 3];
+            const int net = pr[8 * q + 2], comp = pr[8 * q + 3], id = pr[8 * q + 4] | (pr[8 * q + 5] << 8);
             if (comp >= h[0] || net >= h[1] || net < prev) return fail(env, PCBENV_EINVAL, "pin record out of range or not net-major");
             if (pr[8 * q] >= cr[8 * comp] || pr[8 * q + 1] >= cr[8 * comp + 1]) return fail(env, PCBENV_EINVAL, "pin outside its component");
+            if (++per_net[net] > PCBENV_MAX_PINS_PER_NET) return fail(env, PCBENV_EINVAL, "too many pins in one net");
+            if (spatial) {  // feature row = the global pin id: a permutation of 0..num_pins-1
+                if (id >= h[2] || (seen[id >> 3] >> (id & 7) & 1)) return fail(env, PCBENV_EINVAL, "pin ids must be a permutation of 0..num_pins-1");
+                seen[id >> 3] |= (unsigned char)(1u << (id & 7));
+            } else if (id >= d.mp) {  // feature row = [component, pin_id]
+                return fail(env, PCBENV_EINVAL, "pin id beyond max_num_pins_per_component");
+            }
             prev = net;
         }
     }

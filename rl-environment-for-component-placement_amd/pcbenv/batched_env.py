@@ -68,6 +68,10 @@ class BatchedPlacementEnv:
         if self.device.type != "cuda":
             raise RuntimeError("BatchedPlacementEnv needs a GPU device (there is no CPU fallback)")
         self._L = _lib.load()
+        # per-environment spaces (the reference constructors' declarations); every tensor adds a leading batch dim
+        from .spaces import action_space_for, observation_space_for
+        self.action_space = self.single_action_space = action_space_for(cfg)
+        self.observation_space = self.single_observation_space = observation_space_for(cfg)
         self.auto_reset = bool(auto_reset)
         self._ccfg = _lib.make_config(cfg, num_envs, queue_depth,
                                       (_lib.FLAG_INCREMENTAL_OBS if incremental_obs else 0)

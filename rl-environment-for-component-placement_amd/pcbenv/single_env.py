@@ -1,9 +1,10 @@
 """SingleEnvAdapter: one environment behind the reference's gym-0.22 surface.
 
 `reset() -> obs dict`, `step(action_tuple) -> (obs, reward: float, done: bool, info: dict)`,
-attributes `action_mask`, `grid`, `height`, `width`, `components`-free instance
-access -- so loops written for the reference (`agent/random/random_policy_*.py`
-`simulate()`, RLlib's `create_env`) run unchanged against the device path.  It is
+attributes `action_space`, `observation_space` (pcbenv/spaces.py: the reference constructors'
+declarations), `action_mask`, `grid`, `height`, `width`, `components`, `actions` -- so loops
+written for the reference (`agent/random/random_policy_*.py` `simulate()`, RLlib's
+`create_env`) run unchanged against the device path.  It is
 a B = 1 `BatchedPlacementEnv`; observations come back as NumPy arrays in the
 reference's dtypes (float64; float32 for the square env) and are fresh copies,
 like the reference's.  Instances come from the reference-exact stream
@@ -19,6 +20,40 @@ import torch
 from .batched_env import BatchedPlacementEnv
 from .config import EnvConfig, KIND_PIN, KIND_SPATIAL, KIND_SQUARE
 from .instances import Instance, InstanceStream
+from .spaces import action_space_for, observation_space_for
+
+
+class _PinView:
+    __slots__ = ("_comp", "_k")
+
+    def __init__(self, comp, k):
+        self._comp, self._k = comp, k
+
+    def _get(self, i):
+        return self._comp._adapter._component_state(self._comp.comp_id)[2][self._k][i]
+
+    relative_x = property(lambda s: s._get(0))
+    relative_y = property(lambda s: s._get(1))
+    absolute_x = property(lambda s: s._get(2))
+    absolute_y = property(lambda s: s._get(3))
+    pin_id = property(lambda s: s._get(4))
+    net_id = property(lambda s: s._get(5))
+    component_id = property(lambda s: s._comp.comp_id)
+
+
+class _ComponentView:
+    """Live stand-in for the reference's `Component` (attribute names of `dummy_env_rectangular_pin.py:108-148`)."""
+    __slots__ = ("_adapter", "comp_id", "h", "w", "area", "pins")
+
+    def __init__(self, adapter, c):
+        ins = adapter.instance
+        self._adapter, self.comp_id = adapter, c
+        self.h, self.w = int(ins.comp_h[c]), int(ins.comp_w[c])
+        self.area = self.h * self.w
+        self.pins = [_PinView(self, k) for k in range(int(np.count_nonzero(ins.pin_comp == c)))] if ins.num_pins else []
+
+    placed = property(lambda s: s._adapter._component_state(s.comp_id)[0])
+    position = property(lambda s: s._adapter._component_state(s.comp_id)[1])
 
 
 class SingleEnvAdapter:
@@ -31,6 +66,11 @@ class SingleEnvAdapter:
         self._stream = InstanceStream(cfg, seed)
         self.instance: Optional[Instance] = None
         self._dtype = np.float32 if cfg.kind == KIND_SQUARE else np.float64
+        self.action_space = action_space_for(cfg)
+        self.observation_space = observation_space_for(cfg)
+        self.actions = []      # every action passed to step() this episode (the spatial reference keeps this list, S:1574)
+        self._placed = []      # (o, x, y) of the valid placements, in component order
+        self._components, self._row_owner = [], {}
 
     def _obs(self) -> Dict[str, np.ndarray]:
         return {k: v[0].cpu().numpy().astype(self._dtype) for k, v in self._env.obs.items()}
@@ -40,11 +80,23 @@ class SingleEnvAdapter:
             self.instance = instance if instance is not None else self._stream.next()
             self._env.load_instances([self.instance])
         self._env.reset()
+        self.actions, self._placed = [], []
+        self._components, self._row_owner = [], {}
+        if self.instance is not None:
+            ins = self.instance
+            if self.cfg.kind == KIND_PIN:  # the last pin in self.pins order owns the feature row [component, pin_id]
+                for q in range(ins.num_pins):
+                    self._row_owner[(int(ins.pin_comp[q]), int(ins.pin_id[q]))] = q
+            self._components = [_ComponentView(self, c) for c in range(ins.num_components)]
         return self._obs()
 
     def step(self, action: Sequence[int], verbose: bool = False):
         a = torch.tensor([list(action)], dtype=torch.int32)
+        valid = self.validate_action(*action)
         self._env.step(a)
+        self.actions.append(tuple(int(v) for v in action))
+        if valid and self.cfg.kind != KIND_SQUARE:
+            self._placed.append(tuple(int(v) for v in action))
         reward = float(self._env.reward[0].item())
         done = bool(self._env.done[0].item())
         info = {}
@@ -73,28 +125,44 @@ class SingleEnvAdapter:
 
     @property
     def components(self):
-        """Read-only view with the reference's attribute names (`Component`: h, w, area, comp_id, placed, position,
-        pins; `Pin`: relative_x/y, absolute_x/y, pin_id, component_id, net_id) built from the instance and the current
-        feature tensors -- what `utils/agent/utils.py:238` reads to save a rollout."""
-        from types import SimpleNamespace
-        if self.instance is None:
-            return []
-        feat = self._env.obs["all_components_feature"][0].cpu().numpy()
-        ins, out = self.instance, []
-        spatial = self.cfg.kind == KIND_SPATIAL
-        pins_num = self._env.obs["all_pins_num_feature"][0].cpu().numpy() if self.cfg.kind in (KIND_PIN, KIND_SPATIAL) else None
-        for c in range(ins.num_components):
-            x, y = int(feat[c, 2]), int(feat[c, 3])
-            pins = []
-            if spatial:  # rows are indexed by the global pin id, so current (rotated) coordinates can be read back
-                for q in np.flatnonzero(ins.pin_comp == c):
-                    r = pins_num[int(ins.pin_id[q])]
-                    pins.append(SimpleNamespace(relative_x=int(r[0]), relative_y=int(r[1]), absolute_x=int(r[2]),
-                                                absolute_y=int(r[3]), pin_id=int(ins.pin_id[q]), component_id=c,
-                                                net_id=int(ins.pin_net[q])))
-            out.append(SimpleNamespace(h=int(ins.comp_h[c]), w=int(ins.comp_w[c]), area=int(ins.comp_h[c] * ins.comp_w[c]),
-                                       comp_id=c, placed=x >= 0, position=(x, y), pins=pins))
-        return out
+        """The reference's `env.components`: one object per component with the reference's attribute names
+        (`Component`: h, w, area, comp_id, placed, position, pins; `Pin`: relative_x/y, absolute_x/y, pin_id,
+        component_id, net_id).  Like the reference's list it is created by `reset()` and its objects are LIVE: a
+        caller that keeps the list from right after `reset()` (`utils/agent/utils.py:238` does) sees the placements
+        when the episode is over.  Every attribute read goes to the device tensors."""
+        return self._components
+
+    def _component_state(self, c: int):
+        """(placed, (x, y), [(rel_x, rel_y, abs_x, abs_y, pin_id, net_id) ...]) of component c, now.  Sizes and positions
+        come from the feature tensors on the device.  Pin coordinates are read back from `all_pins_num_feature`
+        wherever a pin owns a row (spatial: row = global pin id; pin env: row [component, pin_id] unless a later pin
+        of the component overwrote it, quirk Q1); the overwritten ones are recomputed from the instance and the
+        recorded placement with `place_component`'s rotation (S:149-190)."""
+        ins = self.instance
+        feat = self._env.obs["all_components_feature"][0, c].cpu().numpy()
+        x, y = int(feat[2]), int(feat[3])
+        h, w = int(ins.comp_h[c]), int(ins.comp_w[c])
+        pin_kind, spatial = self.cfg.kind in (KIND_PIN, KIND_SPATIAL), self.cfg.kind == KIND_SPATIAL
+        pins = []
+        if pin_kind:
+            pins_num = self._env.obs["all_pins_num_feature"][0].cpu().numpy()
+            for q in np.flatnonzero(ins.pin_comp == c):
+                pid = int(ins.pin_id[q])
+                if spatial or self._row_owner[(c, pid)] == q:
+                    rx, ry, ax, ay = (int(v) for v in (pins_num[pid] if spatial else pins_num[c, pid]))
+                else:
+                    rx, ry, ax, ay = int(ins.pin_rel_x[q]), int(ins.pin_rel_y[q]), -1, -1
+                    if c < len(self._placed):
+                        o, px, py = self._placed[c]
+                        if o == 1:
+                            rx, ry = ry, h - rx - 1
+                        elif o == 2:
+                            rx, ry = h - rx - 1, w - ry - 1
+                        elif o == 3:
+                            rx, ry = w - ry - 1, rx
+                        ax, ay = px + rx, py + ry
+                pins.append((rx, ry, ax, ay, pid, int(ins.pin_net[q])))
+        return x >= 0, (x, y), pins
 
     def close(self):
         self._env.close()

@@ -16,6 +16,8 @@ from typing import Tuple
 
 import numpy as np
 
+from .spaces import flat_action_space, flat_mask_observation_space
+
 
 def flat_to_tuple(action: int, num_orientations: int, height: int, width: int) -> Tuple[int, ...]:
     """Index math of FlatteningActionWrapperRect.action / ...Square.action."""
@@ -43,7 +45,13 @@ class _Wrapper:
 
 
 class FlatteningActionMaskObservationWrapper(_Wrapper):
-    """`action_mask` flattened to `[..., O*H*W]` (a view, no copy)."""
+    """`action_mask` flattened to `[..., O*H*W]` (a view, no copy); `observation_space` likewise
+    (`env_wrappers.py:28-31`)."""
+
+    def __init__(self, env):
+        super().__init__(env)
+        self.observation_space = flat_mask_observation_space(env.observation_space)
+        self.action_space = env.action_space
 
     def _obs(self, obs):
         out = dict(obs)
@@ -63,7 +71,14 @@ class FlatteningActionMaskObservationWrapper(_Wrapper):
 
 class FlatteningActionWrapper(_Wrapper):
     """Accepts flat actions.  Batched: an int tensor `[B]` goes to the kernel as PCBENV_ACTION_FLAT.
-    Single env: a Python int is decoded with the reference's divmod chain."""
+    Single env: a Python int is decoded with the reference's divmod chain.  `action_space` is
+    `Discrete(prod(factor sizes))` (`env_wrappers.py:76-78`)."""
+
+    def __init__(self, env):
+        super().__init__(env)
+        self.factor_sizes = [sp.n for sp in env.action_space.spaces]
+        self.action_space = flat_action_space(env.action_space)
+        self.observation_space = env.observation_space
 
     def action(self, action):
         cfg = self.env.cfg

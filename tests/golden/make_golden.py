@@ -18,7 +18,8 @@ action-independent.  Per case it stores, in `tests/golden/<case>.npz`:
 * per step the action, reward (float64), done, info values,
 * the full observation after reset and after every step (0/1 arrays bit-packed).
 
-Also written: `norm2.npz` (np.linalg.norm of length-2 vectors in this container's
+Also written: `spaces.json` (the gym spaces every reference constructor declares), `adapter_views.npz` (`env.components`
+with all pin coordinates after whole episodes), `norm2.npz` (np.linalg.norm of length-2 vectors in this container's
 NumPy/OpenBLAS -- SURVEY.md trap T1) and `setorder.npz` (CPython iteration order of
 `set(points) - visited` -- trap T2).  The files are data only; no reference source
 text is stored.
@@ -191,6 +192,72 @@ def record_setorder():
                         order=np.array(orders), tuple_hash=np.array(hashes, np.uint64))
 
 
+def _describe_space(sp):
+    """JSON summary of one of the reference's space objects (the stand-in gym classes keep the ctor arguments)."""
+    from gym import spaces as gs
+    if isinstance(sp, gs.Discrete):
+        return {"type": "Discrete", "n": int(sp.n)}
+    if isinstance(sp, gs.Tuple):
+        return {"type": "Tuple", "spaces": [_describe_space(x) for x in sp.spaces]}
+    if isinstance(sp, gs.Box):
+        return {"type": "Box", "low": float(np.min(sp.low)), "high": float(np.max(sp.high)),
+                "shape": [int(v) for v in sp.shape], "dtype": str(np.dtype(sp.dtype))}
+    if isinstance(sp, gs.Dict):
+        return {"type": "Dict", "spaces": {k: _describe_space(v) for k, v in sp.spaces.items()}}
+    raise TypeError(sp)
+
+
+def record_spaces():
+    """action_space / observation_space exactly as each reference constructor declares them, for every case above
+    (`tests/golden/spaces.json`; compared with pcbenv/spaces.py by tests/test_spaces.py)."""
+    out = {}
+    for name, kind, args, seeds, _eps, _p in CASES:
+        np.random.seed(seeds[0])
+        random.seed(seeds[0])
+        env = REF[kind](*args)
+        out[name] = {"kind": kind, "args": list(args), "action_space": _describe_space(env.action_space),
+                     "observation_space": _describe_space(env.observation_space)}
+    with open(os.path.join(HERE, "spaces.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+
+
+def record_adapter_views():
+    """What callers read off the environment OBJECT rather than the observation: `env.components` (with every pin's
+    coordinates, what utils/agent/utils.py:238 pickles) and `env.action_mask` after whole episodes, for the small
+    pin / spatial cases (`tests/golden/adapter_views.npz`; replayed on the HIP path through SingleEnvAdapter)."""
+    data = {}
+    meta = []
+    for name, kind, args, seeds, episodes, _p in CASES:
+        if name not in ("pin_small_centroid", "spatial_small_centroid", "pin_mid_beam_k1"):
+            continue
+        meta.append({"name": name, "kind": kind, "args": list(args), "seeds": list(seeds[:4]), "episodes": 2})
+        for seed in seeds[:4]:
+            np.random.seed(seed)
+            random.seed(seed)
+            env = REF[kind](*args)
+            arng = random.Random(seed + 777)
+            for ep in range(2):
+                pre = f"{name}_s{seed}_e{ep}_"
+                env.reset()
+                for k, v in tables(env, kind).items():
+                    data[pre + k] = v
+                actions, done = [], False
+                while not done:
+                    valid = np.argwhere(env.action_mask == 1)
+                    act = tuple(int(v) for v in valid[arng.randrange(len(valid))])
+                    _, _, done, _ = env.step(act)
+                    actions.append(act)
+                data[pre + "actions"] = np.array(actions, np.int16)
+                data[pre + "comp_state"] = np.array([[c.h, c.w, c.area, c.comp_id, int(c.placed), c.position[0], c.position[1]]
+                                                     for c in env.components], np.int16)
+                data[pre + "pin_state"] = np.array([[c.comp_id, p.relative_x, p.relative_y, p.absolute_x, p.absolute_y,
+                                                     p.pin_id, p.component_id, p.net_id]
+                                                    for c in env.components for p in c.pins], np.int16).reshape(-1, 8)
+                data[pre + "action_mask_sum"] = np.array(env.action_mask.sum(), np.float64)
+    data["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(HERE, "adapter_views.npz"), **data)
+
+
 if __name__ == "__main__":
     total = 0
     for case in CASES:
@@ -199,4 +266,6 @@ if __name__ == "__main__":
         print(f"{case[0]:28s} {sz / 1024:8.1f} KiB")
     record_norm2()
     record_setorder()
+    record_spaces()
+    record_adapter_views()
     print(f"total {total / 1024:.1f} KiB")

@@ -184,3 +184,46 @@ def reward_scenarios(orc):
     cfg.reward_type = "both"
     r, _, _ = orc.find_reward(cfg, nets, placed_all=False)                      # :382-391
     assert np.isclose(r, -0.5 * 2 * math.sqrt(2) - 0.5 * 24 / 8)
+
+
+# ---- the same reward KATs through reset(instance) / step(action) --------------------------------------------
+def reward_instance(kind="pin"):
+    """The hand-built instance of pin_environment/test_env.py:199-379 (conftest.py:68-117, :266-283) as something
+    `reset(instance)` + five `step`s reach: the reference test sets `absolute_x/y` of seven pins by hand; here five
+    components (3x3, 3x3, 2x1, 2x1, 2x2) are placed unrotated at (0,0), (3,2), (4,1), (7,5), (8,0) so that the pins
+    land on exactly those cells, in the same net order (reference nets 1, 2 -> nets 0, 1).  One relative coordinate
+    differs from the fixture's: the second pin of component 2 is (2,1) instead of (2,0), because the fixture's two
+    hand-set absolute positions of that component imply two different component positions."""
+    comps = [(3, 3), (3, 3), (2, 1), (2, 1), (2, 2)]
+    #         rel_x rel_y net comp
+    pins = [(0, 2, 0, 0), (2, 1, 0, 1), (0, 1, 0, 4),              # net 0: (0,2) (5,3) (8,1)
+            (2, 0, 1, 0), (0, 2, 1, 1), (0, 0, 1, 2), (0, 0, 1, 3)]  # net 1: (2,0) (3,4) (4,1) (7,5)
+    ids = list(range(7)) if kind == "spatial" else [0] * 7          # the fixture gives every pin pin_id 0 (pin env)
+    placements = [(0, 0, 0), (0, 3, 2), (0, 4, 1), (0, 7, 5), (0, 8, 0)]
+    return inst(comps, [p + (i,) for p, i in zip(pins, ids)], 2), placements
+
+
+def reward_env_scenarios(make, reference_values=None):
+    """pin_environment/test_env.py:199-391: find_reward for beam / centroid / both and the worst case, reached through
+    the public surface.  `reference_values(rt) -> (reward, wl, ni)`: optional exact (bit-level) expectation."""
+    norm = min(3 * 3 * 3.5, 2 * 4)
+    wl_beam = (np.sqrt(26) + np.sqrt(13) + np.sqrt(17) + np.sqrt(10) + np.sqrt(5)) / 20
+    wl_cen = (13 / 3 + np.sqrt(13) / 3 + np.sqrt(130) / 3 + np.sqrt(41) / 2 + 3 / 2 + np.sqrt(61) / 2 + np.sqrt(13) / 2) / 20
+    instance, placements = reward_instance("pin")
+    for rt, wl, ni in (("beam", wl_beam, 1), ("centroid", wl_cen, 2), ("both", wl_beam, 1)):
+        env = make(EnvConfig.pin(10, 10, 1, 1, 2, 4, 2, 4, 5, 2, 4, 4, 2, 2, rt, 2, 0.5))
+        env.reset(instance)
+        for k, a in enumerate(placements):
+            obs, r, d, info = env.step(a)
+            assert d == (k == 4) and (r == 0.0 or k == 4), (rt, k)
+        assert np.isclose(r, -0.5 * (wl + ni / norm)), (rt, r)                     # :199-379
+        assert np.isclose(info["wirelength"], wl) and np.isclose(info["num_intersections"], ni / norm), (rt, info)
+        if reference_values is not None:
+            want = reference_values(rt)
+            got = (r, info["wirelength"], info["num_intersections"])
+            assert np.array_equal(np.array(got).view(np.uint64), np.array(want).view(np.uint64)), (rt, got, want)
+    env = make(EnvConfig.pin(10, 10, 1, 1, 2, 4, 2, 4, 5, 2, 4, 4, 2, 2, "both", 2, 0.5))
+    env.reset(instance)
+    obs, r, d, info = env.step((0, 9, 9))                                             # :382-391: not all placed
+    assert d and np.isclose(r, -0.5 * 2 * math.sqrt(2) - 0.5 * 24 / 8)
+    assert info == {"wirelength": 0.5 * math.sqrt(200) * 8, "num_intersections": 24.0}  # the raw upper bounds (P:907-908)

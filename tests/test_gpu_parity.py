@@ -72,9 +72,11 @@ def test_golden_episodes_on_gpu(name):
 
 
 def _oracle_rollout(cfg, B, episodes, queue_depth=2, p_bad=0.02, incremental=False, auto_reset=False, fused=False,
-                    threads=0):
+                    threads=0, cpu_threads=1, stats=None, max_steps=400):
     """Device-sampled legal actions (plus a few corrupted ones); every observation, reward, done, info of every step
-    must equal the CPU oracle's.  Covers reset_done() and the instance queue."""
+    must equal the CPU oracle's.  Covers reset_done() and the instance queue.  cpu_threads > 1: the oracle steps and
+    the whole-batch tensor comparison run under OpenMP (full-size batches).  stats: filled with counts of the
+    terminal kinds seen."""
     from oracle import oracle as orc
     env = BatchedPlacementEnv(cfg, B, queue_depth=queue_depth, run_seed=3, incremental_obs=incremental,
                               auto_reset=auto_reset, threads_per_env=threads)
@@ -87,18 +89,21 @@ def _oracle_rollout(cfg, B, episodes, queue_depth=2, p_bad=0.02, incremental=Fal
             for i in np.flatnonzero(mask):
                 ob.env(i).reset()
             return
-        rec = np.stack([packed[cursor[i] % queue_depth][i] for i in range(B)])
-        ob.reset_packed(rec, mask.astype(np.uint8))
+        rec = np.where((cursor % queue_depth == 0)[:, None], packed[0], packed[1 % queue_depth]) if queue_depth <= 2 else \
+            np.stack([packed[cursor[i] % queue_depth][i] for i in range(B)])
+        ob.reset_packed(rec, mask.astype(np.uint8), cpu_threads)
         cursor[mask.astype(bool)] += 1
 
     env.reset()
     oracle_reset(np.ones(B, np.uint8))
+    if stats is not None:
+        stats.update(worst_case_terminals=0, routed_terminals=0, env_steps=0)
     rng = np.random.RandomState(5)
     steps = 0
     done_eps = 0
     t = 0
     keys = list(env.obs.keys())
-    while done_eps < episodes * B and t < 400:
+    while done_eps < episodes * B and t < max_steps:
         if fused:
             sampled = env.sample_actions(t).cpu().numpy()  # must equal what the fused launch draws
             o, r, d, _, a_dev = env.rollout_step(t)
@@ -109,7 +114,11 @@ def _oracle_rollout(cfg, B, episodes, queue_depth=2, p_bad=0.02, incremental=Fal
             bad = rng.rand(B) < p_bad
             a[bad] = rng.randint(-1, 70, size=(int(bad.sum()), 3))
             o, r, d, _ = env.step(torch.from_numpy(a))
-        rr, dd, ii = ob.step(a)
+        rr, dd, ii = ob.step(a, cpu_threads)
+        if stats is not None and cfg.kind in (KIND_PIN, KIND_SPATIAL):
+            worst = dd.astype(bool) & (ii[:, 0] == cfg.max_wirelength) & (ii[:, 1] == cfg.max_num_intersections)
+            stats["worst_case_terminals"] += int(worst.sum())
+            stats["routed_terminals"] += int(dd.sum() - worst.sum())
         if auto_reset:  # observations already show the next episode of the environments that finished
             oracle_reset(dd)
         obs = _host(o)
@@ -119,10 +128,15 @@ def _oracle_rollout(cfg, B, episodes, queue_depth=2, p_bad=0.02, incremental=Fal
         if cfg.kind in (KIND_PIN, KIND_SPATIAL):
             has = ~np.isnan(inf[:, 0])
             assert _same_bits(inf[has], ii[has]), t
-        for i in range(B):
-            want = ob.env(i).obs()
+        if cpu_threads > 1:  # whole batch, every tensor, compared inside the oracle library under OpenMP
             for k in keys:
-                assert np.array_equal(obs[k][i].astype(np.float64), want[k]), (t, i, k)
+                bad = ob.first_mismatch(k, obs[k], cpu_threads)
+                assert bad < 0, (t, bad, k)
+        else:
+            for i in range(B):
+                want = ob.env(i).obs()
+                for k in keys:
+                    assert np.array_equal(obs[k][i].astype(np.float64), want[k]), (t, i, k)
         done_eps += int(d.sum())
         if not auto_reset:
             env.reset_done()
@@ -130,6 +144,8 @@ def _oracle_rollout(cfg, B, episodes, queue_depth=2, p_bad=0.02, incremental=Fal
         steps += B
         t += 1
     env.close()
+    if stats is not None:
+        stats["env_steps"] = steps
     return steps
 
 
@@ -381,6 +397,42 @@ def test_full_size_batches(name, B):
             cursor += 1
             ob.reset_packed(packed[cursor % 2][idx], d.astype(np.uint8))
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("name,B,stream_mb", [
+    ("c2", 1024, None), ("c3", 4096, None), ("c3", 4096, 0), ("c4", 4096, None), ("c4", 4096, 0),
+    ("c5", 8192, None), ("c5", 2048, 1 << 20)])
+def test_every_tensor_at_the_baseline_batches(name, B, stream_mb, monkeypatch):
+    """BASELINE.json's batch sizes, one whole episode (plus the reset that follows it) in the bench's own mode (fused
+    sampling + in-launch reset): EVERY observation tensor, reward, done and info of EVERY environment at every step
+    against the CPU oracle.  stream_mb forces the other store flavour (0: streaming `sc1 nt` stores below the
+    Infinity-Cache threshold; 1 << 20: write-through `sc1` stores for a c5 batch that would otherwise stream)."""
+    if stream_mb is not None:
+        monkeypatch.setenv("PCBENV_STREAM_THRESHOLD_MB", str(stream_mb))
+    cfg = named_config(name)
+    stats = {}
+    n = _oracle_rollout(cfg, B, episodes=1, queue_depth=2, p_bad=0.0, auto_reset=True, fused=True, cpu_threads=16,
+                        stats=stats, max_steps=cfg.max_num_components + 2)
+    assert n >= B * cfg.max_num_components
+    if cfg.kind in (KIND_PIN, KIND_SPATIAL):
+        assert stats["routed_terminals"] >= B
+
+
+@pytest.mark.parametrize("threads,incremental", [(256, True), (256, False), (64, True)])
+def test_no_legal_cell_terminals_with_in_launch_reset(threads, incremental):
+    """Crowded grids (12x12, eight components of up to 5x5): many episodes end because the NEXT component has no legal
+    cell (Q8 ii), so the step's own grid / pin_grid / mask stores are not skipped and the in-launch reset rewrites the
+    same bytes from other lanes and -- threads_per_env = 256 -- other wavefronts.  Every tensor against the oracle."""
+    cfg = EnvConfig.spatial(12, 12, 5, 5, 2, 5, 2, 5, 8, 8, 3, 5, 7, 2, "centroid", 2, 0.5)
+    stats = {}
+    _oracle_rollout(cfg, 512, episodes=6, queue_depth=2, p_bad=0.0, incremental=incremental, auto_reset=True,
+                    fused=True, threads=threads, cpu_threads=8, stats=stats, max_steps=60)
+    assert stats["worst_case_terminals"] > 200 and stats["routed_terminals"] > 20, stats
+    cfgp = EnvConfig.pin(12, 12, 5, 5, 2, 5, 2, 5, 8, 8, 3, 5, 7, 2, "both", 2, 0.5)
+    stats = {}
+    _oracle_rollout(cfgp, 256, episodes=4, queue_depth=2, p_bad=0.0, incremental=incremental, auto_reset=True,
+                    fused=True, threads=threads, cpu_threads=8, stats=stats, max_steps=40)
+    assert stats["worst_case_terminals"] > 50, stats
 
 
 def test_flat_actions_equal_tuple_actions():

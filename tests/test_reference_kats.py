@@ -27,6 +27,17 @@ def test_reward_chain_kats_oracle():
     K.reward_scenarios(orc)
 
 
+def _oracle_find_reward(rt):
+    """The oracle's stand-alone find_reward on the KAT's pin positions (pinned by reward_scenarios above)."""
+    from pcbenv import EnvConfig
+    cfg = EnvConfig.pin(10, 10, 1, 1, 2, 4, 2, 4, 5, 2, 4, 4, 2, 2, rt, 2, 0.5)
+    return orc.find_reward(cfg, [[(0, 2), (5, 3), (8, 1)], [(2, 0), (3, 4), (4, 1), (7, 5)]])
+
+
+def test_reward_kats_through_reset_and_step_oracle():
+    K.reward_env_scenarios(_oracle, _oracle_find_reward)
+
+
 def _gpu(cfg):
     from pcbenv.single_env import SingleEnvAdapter
     return SingleEnvAdapter(cfg)
@@ -46,6 +57,13 @@ def test_rect_kats_hip():
 def test_pin_kats_hip():
     K.pin_scenarios(_gpu, "pin")
     K.pin_scenarios(_gpu, "spatial")
+
+
+@pytest.mark.gpu
+def test_reward_kats_through_reset_and_step_hip():
+    """/root/reference/tests/pin_environment/test_env.py:199-391 (find_reward beam / centroid / both, worst case) on
+    the HIP path: the hand-built instance through reset(instance) + step, bit-equal to the oracle's find_reward."""
+    K.reward_env_scenarios(_gpu, _oracle_find_reward)
 
 
 @pytest.mark.gpu

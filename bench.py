@@ -41,6 +41,51 @@ def algorithmic_bytes_per_env_step(cfg) -> int:
     return b
 
 
+def trajectory_bytes_per_env_step(cfg) -> int:
+    """Bytes one step writes in the trajectory layout: every tensor of the slot, whole (cells + the float64 feature
+    tensors + component_grid), plus the state tables it reads and writes once per launch (not counted per step)."""
+    from pcbenv.batched_env import obs_spec
+    import math
+    total = 0
+    for shape, dt in obs_spec(cfg).values():
+        total += math.prod(shape) * (1 if dt == torch.uint8 else 8)
+    return total + 8 + 1 + 16  # reward, done, info
+
+
+def rollout_leg(cfg, args, B, dev_index, rank, T):
+    """The persistent rollout (pcbenv_rollout_sampled): T steps per launch, state held in LDS, every step's tensors kept
+    in their own slot of [T + 1, B, ...] buffers -- the on-device counterpart of the reference's simulate() loop."""
+    from pcbenv.batched_env import BatchedPlacementEnv
+    S = T + 1
+    env = BatchedPlacementEnv(cfg, B, device=f"cuda:{dev_index}", queue_depth=max(args.queue_depth, 4), run_seed=args.run_seed,
+                              first_env_index=rank * B, auto_reset=True, threads_per_env=args.threads_per_env, num_slots=S)
+    env.generate_instances()
+    env.reset()
+    acts = torch.empty((T, B, 3), dtype=torch.int32, device=env.device)
+    launches = max(1, args.steps // T)
+    pos = 1
+    for _ in range(2):  # warm-up launches
+        env.select_slot(pos); env.rollout_steps(0, T, out=acts); pos = (pos + T) % S
+    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev[0].record()
+    for k in range(launches):
+        env.select_slot(pos); env.rollout_steps((2 + k) * T, T, out=acts); pos = (pos + T) % S
+    ev[1].record()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kernel_ms = ev[0].elapsed_time(ev[1]) / launches
+    nbytes = trajectory_bytes_per_env_step(cfg)
+    env.close()
+    gbps = nbytes * B * T / (kernel_ms * 1e-3) / 1e9
+    return {"value": round(B * T * launches / dt, 1), "unit": "env-steps/s", "steps_per_launch": T, "num_slots": S,
+            "launches": launches, "ms_per_step": round(dt / (launches * T) * 1e3, 5), "kernel_ms_per_launch": round(kernel_ms, 4),
+            "bytes_written_per_env_step": nbytes, "achieved_GBps": round(gbps, 1), "frac_of_8TBps": round(gbps / 8000.0, 4),
+            "algorithmic_GBps": round(algorithmic_bytes_per_env_step(cfg) * B * T / (kernel_ms * 1e-3) / 1e9, 1),
+            "note": "every tensor of every step kept (trajectory layout), float64 feature tensors included; this rank only"}
+
+
 def host_cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -156,6 +201,9 @@ def main():
                          "(the PPO-side collective, 256 KiB per rank at 4 096 envs) over RCCL")
     ap.add_argument("--no-adv-allgather", dest="adv_allgather", action="store_false")
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; `value` comes from the first, the spread of all is reported")
+    ap.add_argument("--rollout-steps", type=int, default=16,
+                    help="also time the persistent rollout kernel with this many steps per launch in the trajectory layout "
+                         "(reported as `rollout`; 0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     args = ap.parse_args()
@@ -288,6 +336,14 @@ def main():
             torch.cuda.synchronize()
             step_kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
 
+    env.close()
+    rollout = None
+    if args.rollout_steps > 0 and not args.incremental and args.config != "c1":
+        if dist:
+            dist.barrier()
+        rollout = rollout_leg(cfg, args, B, dev_index, rank, args.rollout_steps)
+        if dist:
+            dist.barrier()
     if rank == 0:
         b_alg = algorithmic_bytes_per_env_step(cfg)
         if args.incremental:
@@ -344,9 +400,8 @@ def main():
                            "instance_generation_s": round(t_gen, 2),
                            "store_policy": "sc1 nt (streaming)" if cfg.cell_tensor_bytes_per_step(args.incremental) * B
                            > int(os.environ.get("PCBENV_STREAM_THRESHOLD_MB", "256")) * (1 << 20) else "sc1 (write-through)"},
-                "roofline": roof, "cpu_baseline": cpu}
+                "roofline": roof, "cpu_baseline": cpu, "rollout": rollout}
         print(json.dumps(line), flush=True)
-    env.close()
     if dist:
         dist.destroy_process_group()
 

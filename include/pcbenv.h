@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define PCBENV_ABI_VERSION 1
+#define PCBENV_ABI_VERSION 2
 
 /* status codes (every function returning int) */
 #define PCBENV_OK 0
@@ -152,6 +152,17 @@ int32_t pcbenv_max_total_pins(const pcbenv_config *cfg);
 
 int pcbenv_bind_buffers(pcbenv *env, const pcbenv_buffers *buffers);
 
+/* Trajectory layout: every tensor of `buffers` is [num_slots, num_envs, ...] (C-contiguous) instead of
+ * [num_envs, ...].  pcbenv_reset / pcbenv_step* write their outputs (observations, reward, done, info, marginals)
+ * into the slot chosen with pcbenv_select_slot (0 after binding); step t of pcbenv_rollout_sampled writes slot
+ * (selected + t) % num_slots.  This is how a rollout loop (RLlib's sampler, the simulate() loops under agent/random) keeps
+ * the observation of every step -- obs[t] -- without copying tensors after each call.  With num_slots > 1 a step
+ * cannot rely on what an earlier step left in its destination, so every bound tensor is written whole (the float64
+ * feature tensors and component_grid included); PCBENV_FLAG_INCREMENTAL_OBS requires num_slots == 1.
+ * pcbenv_bind_buffers(env, b) == pcbenv_bind_buffers_slots(env, b, 1). */
+int pcbenv_bind_buffers_slots(pcbenv *env, const pcbenv_buffers *buffers, int32_t num_slots);
+int pcbenv_select_slot(pcbenv *env, int32_t slot);
+
 /* Copies n packed instance records (host memory) into queue slot `slot`
  * (0 <= slot < queue_depth) of environments env_ids[0..n) (env_ids == NULL:
  * environments 0..n-1).  Synchronous with respect to `stream`. */
@@ -180,9 +191,14 @@ int pcbenv_sample_actions(pcbenv *env, int32_t *actions_dev, int32_t action_form
 int pcbenv_step_sampled(pcbenv *env, int32_t *actions_out_dev, int32_t action_format, uint64_t seed,
                         uint64_t first_env_index, uint64_t step_index, void *stream);
 
-/* num_steps consecutive pcbenv_step_sampled calls issued from C (no per-step host round trip): step t draws with
- * step_index0 + t and records its actions in actions_out_dev[t] (int32 [num_steps, num_envs, 3] or
- * [num_steps, num_envs] for the flat format).  Intended with PCBENV_FLAG_AUTO_RESET. */
+/* num_steps consecutive pcbenv_step_sampled transitions in ONE persistent kernel launch: the per-environment
+ * state stays in LDS between the steps (no reload, no launch latency per step), step t draws with step_index0 + t
+ * -- the same action pcbenv_step_sampled would draw -- records it in actions_out_dev[t] (int32
+ * [num_steps, num_envs, 3], or [num_steps, num_envs] for the flat format) and writes its outputs into slot
+ * (selected + t) % num_slots.  The counterpart of the reference's simulate() loop
+ * (agent/random/random_policy_square.py:25-58).  Intended with PCBENV_FLAG_AUTO_RESET; every environment may consume
+ * up to one queued instance per terminal transition, so queue_depth bounds the resets per environment between
+ * refills.  (With PCBENV_FLAG_INCREMENTAL_OBS the steps are separate launches.) */
 int pcbenv_rollout_sampled(pcbenv *env, int32_t *actions_out_dev, int32_t action_format, int32_t num_steps,
                            uint64_t seed, uint64_t first_env_index, uint64_t step_index0, void *stream);
 

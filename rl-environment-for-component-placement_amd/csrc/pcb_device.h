@@ -25,22 +25,35 @@ struct DevParams {
     unsigned flags, bind_gen;
     double w_wl, w_int, max_wl, max_int, wl_norm, int_norm, area;
     long long stateStride, instStride;
-    int offOcc, offVm, offComps, offPins;   // byte offsets inside a state block
+    int offOcc, offVm, offComps, offPins, offRank;   // byte offsets inside a state block
     int ldsHf, ldsCls, ldsSeg, ldsBytes;    // byte offsets of LDS scratch behind the state mirror
     unsigned char *state, *queue;
     pcbenv_buffers buf;
     unsigned long long *dbg;                // diagnostic build only (-DPCBENV_STAMPS): [B][32] s_memtime stamps
-    int stream_stores;                      // observation stores bypass the caches (`nt`): see STORE16.  (Last, so that
-                                            // the kernarg offsets of the fields every wave loads first stay put.)
+    int stream_stores;                      // observation stores bypass the caches (`nt`): see STORE16.  (Behind the
+                                            // fields every wave loads first, so that their kernarg offsets stay put.)
+    // Trajectory layout (pcbenv_bind_buffers_slots): every bound tensor is [num_slots, B, ...]; a launch writes its
+    // outputs into `slot` (the persistent rollout kernel: one slot per step).  With num_slots > 1 nothing may rely on
+    // what an earlier step left in the destination, so the float64 feature tensors are written whole every step.
+    int num_slots, slot;
 };
 // In-kernel stamps (cdna_hip_programming.md §7): only in a separate diagnostic build, written to a buffer nothing
 // else reads; `PCBENV_STAMPS=1` in the environment allocates it, tools/kernel_stamps.py prints the phase profile.
 #ifdef PCBENV_STAMPS
 #define STAMP(k) do { if (threadIdx.x == 0 && p.dbg) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); p.dbg[(size_t)blockIdx.x * 32 + (k)] = t_; } } while (0)
 #define STAMP_RT(k) do { if (threadIdx.x == 0 && p.dbg) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); p.dbg[(size_t)blockIdx.x * 32 + (k)] = t_; } } while (0)
+// accumulate elapsed shader cycles of a region / an arbitrary value into slot k (the kernel's first STAMP must zero it)
+#define STAMP_T0() unsigned long long st0_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st0_) :: "memory")
+#define STAMP_ACC_SINCE(k, dep) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : "v"(dep) : "memory"); if (threadIdx.x == 0 && p.dbg) p.dbg[(size_t)blockIdx.x * 32 + (k)] += t_ - st0_; } while (0)
+#define STAMP_ADD(k, v) do { if (threadIdx.x == 0 && p.dbg) p.dbg[(size_t)blockIdx.x * 32 + (k)] += (unsigned long long)(v); } while (0)
+#define STAMP_ZERO(k) do { if (threadIdx.x == 0 && p.dbg) p.dbg[(size_t)blockIdx.x * 32 + (k)] = 0ull; } while (0)
 #else
 #define STAMP(k) do { } while (0)
 #define STAMP_RT(k) do { } while (0)
+#define STAMP_T0() do { } while (0)
+#define STAMP_ACC_SINCE(k, dep) do { } while (0)
+#define STAMP_ADD(k, v) do { } while (0)
+#define STAMP_ZERO(k) do { } while (0)
 #endif
 
 // per-environment header at the start of a state block
@@ -63,7 +76,7 @@ struct __attribute__((aligned(16))) EnvHdr {
 static_assert(sizeof(EnvHdr) == HDR_BYTES, "header size");
 
 // 8-byte records (state block and instance wire format share the pin layout up to abs_x/abs_y)
-struct CompRec { unsigned char h, w; signed char px, py; unsigned char pad[4]; };
+struct CompRec { unsigned char h, w; signed char px, py; unsigned char o, pad[3]; };  // o = orientation it was placed with
 struct PinRec { unsigned char rel_x, rel_y; signed char abs_x, abs_y; unsigned char net, comp; unsigned short id; };
 #define PIN_ID_MASK 0x7FFF
 #define PIN_LOSER 0x8000  // pin env quirk Q1: a later pin of the same component shares this feature row

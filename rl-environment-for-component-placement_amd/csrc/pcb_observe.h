@@ -7,9 +7,11 @@
 // shared pieces of reset / step
 // ----------------------------------------------------------------------------------------------
 struct Lds {
-    EnvHdr *hdr; u64 *occ, *vm; CompRec *comps; PinRec *pins;
+    EnvHdr *hdr; u64 *occ, *vm; CompRec *comps; PinRec *pins; unsigned char *rank;
     u64 *hf; unsigned char *cls; double *seg;
 };
+// Row of environment e in the [num_slots, B, ...] output tensors for the slot a step writes (DevParams::slot).
+__device__ inline int out_row(const DevParams &p, int slot, int e) { return slot * p.B + e; }
 __device__ inline Lds carve(unsigned char *smem, const DevParams &p) {
     Lds l;
     l.hdr = (EnvHdr *)smem;
@@ -17,6 +19,7 @@ __device__ inline Lds carve(unsigned char *smem, const DevParams &p) {
     l.vm = (u64 *)(smem + p.offVm);
     l.comps = (CompRec *)(smem + p.offComps);
     l.pins = (PinRec *)(smem + p.offPins);
+    l.rank = smem + p.offRank;  // rank[q] = position of pin q among the pins of its component (self.pins order)
     l.hf = (u64 *)(smem + p.ldsHf);
     l.cls = smem + p.ldsCls;
     l.seg = (double *)(smem + p.ldsSeg);
@@ -38,22 +41,22 @@ __device__ inline void store_state(const unsigned char *smem, const DevParams &p
 
 // Marginals of the legal mask for factorised policies (factorized_action_distributions.py:358, :401): per
 // orientation "any legal cell" and per (orientation, row) "any legal column", read off the bit rows in LDS.
-template <int KIND, int WW> __device__ inline void emit_marginals(const DevParams &p, Lds &l, int e, int lane) {
+template <int KIND, int WW> __device__ inline void emit_marginals(const DevParams &p, Lds &l, int row, int lane) {
     if (!p.buf.mask_rows && !p.buf.mask_orientation) return;
     const int H = p.H, plane = H * WW, O = p.O;
     for (int i = lane; i < O * H; i += NT) {
         const int o = i / H, r = i - o * H;
-        const u64 *row = l.vm + (o & 1) * plane + r * WW;
+        const u64 *bits = l.vm + (o & 1) * plane + r * WW;
         bool a = false;
-        for (int w = 0; w < WW; w++) a |= row[w] != 0;
-        if (p.buf.mask_rows) p.buf.mask_rows[(size_t)e * O * H + i] = a ? 1 : 0;
+        for (int w = 0; w < WW; w++) a |= bits[w] != 0;
+        if (p.buf.mask_rows) p.buf.mask_rows[(size_t)row * O * H + i] = a ? 1 : 0;
     }
     if (p.buf.mask_orientation) {
         for (int o = (int)(lane / WAVE); o < O; o += NT / WAVE) {  // one wavefront per orientation
             bool a = false;
             for (int i = (lane & 63); i < plane; i += WAVE) a |= l.vm[(o & 1) * plane + i] != 0;
             a = __any(a);
-            if ((lane & 63) == 0) p.buf.mask_orientation[(size_t)e * O + o] = a ? 1 : 0;
+            if ((lane & 63) == 0) p.buf.mask_orientation[(size_t)row * O + o] = a ? 1 : 0;
         }
     }
 }
@@ -62,16 +65,16 @@ template <int KIND, int WW> __device__ inline void emit_marginals(const DevParam
 // [gr0, gr1) and the action_mask planes, each written as soon as its bits exist so that the HBM write stream
 // starts before the second orientation is folded.  Returns "some action is legal".
 template <int KIND, int WW>
-__device__ inline bool mask_and_emit(const DevParams &p, Lds &l, int e, int lane, bool emit, int gr0, int gr1) {
+__device__ inline bool mask_and_emit(const DevParams &p, Lds &l, int row, int lane, bool emit, int gr0, int gr1) {
     const int H = p.H, W = p.W, HW = H * W, plane = H * WW;
     const int cur = l.hdr->cur;
-    unsigned char *m = (emit && p.buf.action_mask) ? p.buf.action_mask + (size_t)e * p.O * HW : 0;
-    if (emit && p.buf.grid) emit_plane<WW>(p.buf.grid + (size_t)e * HW, l.occ, gr0, gr1, W, lane, p.stream_stores);
+    unsigned char *m = (emit && p.buf.action_mask) ? p.buf.action_mask + (size_t)row * p.O * HW : 0;
+    if (emit && p.buf.grid) emit_plane<WW>(p.buf.grid + (size_t)row * HW, l.occ, gr0, gr1, W, lane, p.stream_stores);
     bool any = false;
     if (KIND == PCBENV_SQUARE) {
         any = window_mask<WW>(l.occ, l.hf, l.vm, H, W, p.component_n, p.component_n, lane, &l.hdr->flag);
         if (m) emit_plane<WW>(m, l.vm, 0, H, W, lane, p.stream_stores);
-        if (emit) emit_marginals<KIND, WW>(p, l, e, lane);
+        if (emit) emit_marginals<KIND, WW>(p, l, row, lane);
         return any;
     }
     const bool four = (KIND == PCBENV_PIN || KIND == PCBENV_SPATIAL);  // S:1852-1853 mask[2] = mask[0], mask[3] = mask[1]
@@ -91,17 +94,17 @@ __device__ inline bool mask_and_emit(const DevParams &p, Lds &l, int e, int lane
         if (m) { emit_plane<WW>(m, l.vm, 0, H, W, lane, p.stream_stores); if (four) emit_plane<WW>(m + 2 * HW, l.vm, 0, H, W, lane, p.stream_stores); }
     }
     if (m) { emit_plane<WW>(m + HW, l.vm + plane, 0, H, W, lane, p.stream_stores); if (four) emit_plane<WW>(m + 3 * HW, l.vm + plane, 0, H, W, lane, p.stream_stores); }
-    if (emit) emit_marginals<KIND, WW>(p, l, e, lane);
+    if (emit) emit_marginals<KIND, WW>(p, l, row, lane);
     return any;
 }
 
 // S:1663-1675 draw_pins: class map (0 empty, 1 occupied without pin, n+2 pin of net n) -> one-hot[:, :, 1:];
 // rows [r0, r1) of the (H, W, K) tensor (a step only changes the rows of the placed rectangle).
-template <int WW> __device__ inline void emit_pin_grid(const DevParams &p, Lds &l, int e, int lane, int r0, int r1) {
+template <int WW> __device__ inline void emit_pin_grid(const DevParams &p, Lds &l, int row, int lane, int r0, int r1) {
     if (!p.buf.pin_grid) return;
     const int W = p.W, HW = p.H * W, K = p.K;
     const int c0 = r0 * W, c1 = r1 * W;
-    unsigned char *dst = p.buf.pin_grid + (size_t)e * HW * K;
+    unsigned char *dst = p.buf.pin_grid + (size_t)row * HW * K;
     const long long b0 = (long long)c0 * K, b1 = (long long)c1 * K;
     for (int i = c0 + lane; i < c1; i += NT) {
         int r = i / W, c = i - r * W;
@@ -144,19 +147,175 @@ template <int WW> __device__ inline void emit_pin_grid(const DevParams &p, Lds &
 }
 
 // Feature rows of one pin (P:72-103 / S:70-104 Pin.calculate_feature): [rel_x, rel_y, abs_x, abs_y]
-template <int KIND> __device__ inline void write_pin_num(const DevParams &p, int e, const PinRec &pr) {
+template <int KIND> __device__ inline void write_pin_num(const DevParams &p, int row_, const PinRec &pr) {
     if (!p.buf.all_pins_num_feature) return;
     int row;
     if (KIND == PCBENV_SPATIAL) row = pr.id & PIN_ID_MASK;
     else { if (pr.id & PIN_LOSER) return; row = pr.comp * p.mp + (pr.id & PIN_ID_MASK); }
-    double *f = p.buf.all_pins_num_feature + ((size_t)e * p.pinRows + row) * 4;
+    double *f = p.buf.all_pins_num_feature + ((size_t)row_ * p.pinRows + row) * 4;
     f[0] = pr.rel_x; f[1] = pr.rel_y; f[2] = pr.abs_x; f[3] = pr.abs_y;
+}
+
+// Scratch tables in the class-map zone (free between two emit_pin_grid calls), spatial env only:
+// pid[c][k] = global id of the k-th pin of component c in self.pins order (0xFFFF = none) -- the tail of
+// all_components_feature (S:203-239); netmask[c][rel_x][rel_y] = nets with a pin on that cell of the component at
+// its UNROTATED relative coordinates -- draw_components (S:1677-1697) runs at reset only, so component_grid never
+// shows the in-place rotation of place_component (quirk Q4): for a placed component the rotation is undone here
+// with the orientation kept in its record.
+struct PinTables { unsigned short *pid; unsigned *netmask; };
+__device__ inline PinTables pin_tables(const DevParams &p, Lds &l) {
+    PinTables t;
+    t.pid = (unsigned short *)l.cls;
+    t.netmask = (unsigned *)(l.cls + ((p.C * p.mp * 2 + 3) & ~3));
+    return t;
+}
+__device__ inline void build_pin_tables(const DevParams &p, Lds &l, int lane) {
+    const PinTables t = pin_tables(p, l);
+    const int np = l.hdr->npins;
+    lds_sync();
+    for (int i = lane; i < p.C * p.mp; i += NT) { t.pid[i] = 0xFFFFu; t.netmask[i] = 0u; }
+    lds_sync();
+    for (int q = lane; q < np; q += NT) {
+        const PinRec pr = l.pins[q];
+        const CompRec cr = l.comps[pr.comp];
+        int rx = pr.rel_x, ry = pr.rel_y;
+        if (cr.px >= 0) {  // inverse of S:149-190 place_component
+            const int ax = rx, ay = ry;
+            if (cr.o == 1) { rx = cr.h - 1 - ay; ry = ax; }
+            else if (cr.o == 2) { rx = cr.h - 1 - ax; ry = cr.w - 1 - ay; }
+            else if (cr.o == 3) { rx = ay; ry = cr.w - 1 - ax; }
+        }
+        t.pid[pr.comp * p.mp + l.rank[q]] = (unsigned short)(pr.id & PIN_ID_MASK);
+        atomicOr(&t.netmask[(int)pr.comp * p.mp + rx * p.mw + ry], 1u << pr.net);
+    }
+    lds_sync();
+}
+// S:1677-1697 draw_components from the tables above: byte (cell, ch) = ch == 0 ? component exists : net ch-1 has a
+// pin on the cell; each byte written once.
+__device__ inline void emit_component_grid(const DevParams &p, Lds &l, int row, int lane) {
+    if (!p.buf.component_grid) return;
+    const PinTables t = pin_tables(p, l);
+    const int nc = l.hdr->ncomp;
+    const int cells = p.mh * p.mw, cgsz = cells * p.K, total = p.C * cgsz;
+    unsigned char *cg = p.buf.component_grid + (size_t)row * total;
+    if ((total & 15) == 0 && (((uintptr_t)cg) & 15) == 0) {
+        const ObsDst d = obs_dst(cg, total);
+        for (int c16 = lane; c16 < total / 16; c16 += NT) {
+            const int bb = c16 * 16;
+            int cell = bb / p.K, ch = bb - cell * p.K;
+            u64 field = ((u64)t.netmask[cell] << 1) | (u64)(cell / cells < nc);  // bit ch = byte value of channel ch
+            u64 lo = 0ull, hi = 0ull;
+            #pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const u64 bit = (field >> ch) & 1ull;
+                if (k < 8) lo |= bit << (8 * k); else hi |= bit << (8 * (k - 8));
+                if (++ch == p.K) { ch = 0; cell++; field = cell < p.C * cells ? (((u64)t.netmask[cell] << 1) | (u64)(cell / cells < nc)) : 0ull; }
+            }
+            STORE16_dyn(d, (unsigned)bb, make_uint4((unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)), p.stream_stores);
+        }
+    } else {
+        for (int i = lane; i < total; i += NT) {
+            const int cell = i / p.K, ch = i - cell * p.K;
+            cg[i] = (unsigned char)(ch == 0 ? (cell / cells < nc) : ((t.netmask[cell] >> (ch - 1)) & 1u));
+        }
+    }
+}
+
+// Every float64 feature tensor of environment `row`, whole, from the state in LDS -- each element written exactly
+// once (no write-after-write inside the launch).  Used when the destination holds nothing of this environment:
+// the trajectory layout (num_slots > 1), where every step lands in a fresh slot.  all_components_feature
+// (R:60-79, S:203-239), placement / component masks (S:1445-1451, :1592-1602; R:275-298), pin features
+// (P:72-103 / S:70-104, quirk Q1 for the pin env, S:1520 last row).  Spatial: build_pin_tables() must have run.
+template <int KIND> __device__ inline void emit_features_full(const DevParams &p, Lds &l, int row, int lane) {
+    if (KIND == PCBENV_SQUARE) return;
+    const int nc = l.hdr->ncomp, np = l.hdr->npins, cur = l.hdr->cur;
+    if (p.buf.all_components_feature) {
+        const PinTables t = pin_tables(p, l);
+        double *cf = p.buf.all_components_feature + (size_t)row * p.C * p.F;
+        for (int i = lane; i < p.C * p.F; i += NT) {
+            const int c = i / p.F, k = i - c * p.F;
+            double v = 0.0;
+            if (c < nc) {
+                const CompRec cr = l.comps[c];
+                if (k == 0) v = cr.h; else if (k == 1) v = cr.w; else if (k == 2) v = cr.px; else if (k == 3) v = cr.py;
+                else if (k == 4) v = (double)(cr.h * cr.w) / p.area;
+                else {
+                    const unsigned id = KIND == PCBENV_SPATIAL ? t.pid[c * p.mp + k - 5] : 0xFFFFu;
+                    v = id == 0xFFFFu ? -1.0 : (double)id;
+                }
+            }
+            cf[i] = v;
+        }
+    }
+    if (p.buf.placement_mask) {
+        double *pm = p.buf.placement_mask + (size_t)row * p.C;
+        for (int c = lane; c < p.C; c += NT) {
+            const bool placed = c < nc && l.comps[c].px >= 0;
+            pm[c] = KIND == PCBENV_RECT ? (placed ? 1.0 : 0.0) : (c >= nc ? 0.0 : placed ? 2.0 : c == cur ? 3.0 : 1.0);
+        }
+    }
+    if (KIND == PCBENV_RECT && p.buf.component_mask) {
+        double *cm = p.buf.component_mask + (size_t)row * p.C;
+        for (int c = lane; c < p.C; c += NT) cm[c] = c < nc ? 1.0 : 0.0;
+    }
+    if (KIND == PCBENV_PIN || KIND == PCBENV_SPATIAL) {
+        double *fn = p.buf.all_pins_num_feature ? p.buf.all_pins_num_feature + (size_t)row * p.pinRows * 4 : 0;
+        double *fc = p.buf.all_pins_cat_feature ? p.buf.all_pins_cat_feature + (size_t)row * p.pinRows * p.catW : 0;
+        if (!fn && !fc) return;
+        if (KIND == PCBENV_SPATIAL) {  // row = global pin id: rows 0..np-1 belong to pins, the others are constant
+            for (int r = np + lane; r < p.pinRows; r += NT) {
+                if (fn) { fn[4 * r] = 0.0; fn[4 * r + 1] = 0.0; fn[4 * r + 2] = 0.0; fn[4 * r + 3] = 0.0; }
+                if (fc) { const double v = r == p.pinRows - 1 ? -1.0 : 0.0; fc[2 * r] = v; fc[2 * r + 1] = v; }
+            }
+            for (int q = lane; q < np; q += NT) {
+                const PinRec pr = l.pins[q];
+                const int r = pr.id & PIN_ID_MASK;
+                if (fn) { fn[4 * r] = pr.rel_x; fn[4 * r + 1] = pr.rel_y; fn[4 * r + 2] = pr.abs_x; fn[4 * r + 3] = pr.abs_y; }
+                if (fc) { fc[2 * r] = pr.net; fc[2 * r + 1] = pr.comp; }
+            }
+        } else if (p.pinRows <= p.H * p.WW * 64) {  // pin env: rows [component, pin_id] through a membership bit map
+            u64 *rowbits = l.hf;
+            lds_sync();
+            for (int i = lane; i < p.H * p.WW; i += NT) rowbits[i] = 0ull;
+            lds_sync();
+            for (int q = lane; q < np; q += NT) {
+                const PinRec pr = l.pins[q];
+                const int r = pr.comp * p.mp + (pr.id & PIN_ID_MASK);
+                atomicOr((unsigned long long *)&rowbits[r >> 6], 1ull << (r & 63));
+            }
+            lds_sync();
+            for (int r = lane; r < p.pinRows; r += NT) {
+                if ((rowbits[r >> 6] >> (r & 63)) & 1ull) continue;
+                if (fn) { fn[4 * r] = 0.0; fn[4 * r + 1] = 0.0; fn[4 * r + 2] = 0.0; fn[4 * r + 3] = 0.0; }
+                if (fc) fc[r] = 0.0;
+            }
+            for (int q = lane; q < np; q += NT) {
+                const PinRec pr = l.pins[q];
+                if (pr.id & PIN_LOSER) continue;  // quirk Q1: the last pin with this [component, pin_id] owns the row
+                const int r = pr.comp * p.mp + (pr.id & PIN_ID_MASK);
+                if (fn) { fn[4 * r] = pr.rel_x; fn[4 * r + 1] = pr.rel_y; fn[4 * r + 2] = pr.abs_x; fn[4 * r + 3] = pr.abs_y; }
+                if (fc) fc[r] = pr.net;
+            }
+            lds_sync();
+        } else {  // more rows than the bit map holds (tiny grids with large components): zero everything, then the rows
+            for (int i = lane; i < p.pinRows * 4; i += NT) if (fn) fn[i] = 0.0;
+            for (int i = lane; i < p.pinRows; i += NT) if (fc) fc[i] = 0.0;
+            __syncthreads();
+            for (int q = lane; q < np; q += NT) {
+                const PinRec pr = l.pins[q];
+                if (pr.id & PIN_LOSER) continue;
+                const int r = pr.comp * p.mp + (pr.id & PIN_ID_MASK);
+                if (fn) { fn[4 * r] = pr.rel_x; fn[4 * r + 1] = pr.rel_y; fn[4 * r + 2] = pr.abs_x; fn[4 * r + 3] = pr.abs_y; }
+                if (fc) fc[r] = pr.net;
+            }
+        }
+    }
 }
 
 // Terminal reward (S:793-929 find_reward), all three reward types, inside the step kernel.
 // ROUTES = false compiles the beam-search code out (reward_type centroid: what every shipped reference config uses).
 template <int KIND, bool ROUTES>
-__device__ inline void terminal_reward(const DevParams &p, Lds &l, int e, int lane) {
+__device__ inline void terminal_reward(const DevParams &p, Lds &l, int row, int lane) {
     const bool placed_all = l.hdr->cur < 0;
     double reward, wl, ni;
     if (!placed_all) {  // S:853-863 worst case: the upper bounds, normalised (spatial: twice, quirk Q3)
@@ -171,8 +330,8 @@ __device__ inline void terminal_reward(const DevParams &p, Lds &l, int e, int la
         reward = -1 * (p.w_wl * wl + p.w_int * ni);
     }
     if (lane == 0) {
-        p.buf.reward[e] = reward;
-        if (p.buf.info) { p.buf.info[2 * e] = wl; p.buf.info[2 * e + 1] = ni; }
+        p.buf.reward[row] = reward;
+        if (p.buf.info) { p.buf.info[2 * (size_t)row] = wl; p.buf.info[2 * (size_t)row + 1] = ni; }
     }
 }
 

@@ -20,8 +20,9 @@ __device__ inline void fetch_instance(const DevParams &p, unsigned qcursor, int 
     for (int r = 0; r < 4; r++) { const int q = lane + r * NT; ir.pin[r] = q < p.P ? prec[q] : 0ull; }
 }
 
-template <int KIND, int WW> __device__ inline void reset_env(const DevParams &p, Lds &l, int e, int lane) {
+template <int KIND, int WW, bool TRAJ> __device__ inline void reset_env(const DevParams &p, Lds &l, int e, int row, int lane) {
     const int H = p.H, W = p.W, HW = H * W;
+    const bool full = TRAJ && p.num_slots > 1;  // trajectory layout: the destination slot holds nothing of this environment yet
     lds_sync();
     // The float64 pin-feature tensors are maintained row-wise (a step rewrites only the placed component's
     // rows), so a reset clears just the rows the finished episode used -- unless these buffers have not been
@@ -32,7 +33,7 @@ template <int KIND, int WW> __device__ inline void reset_env(const DevParams &p,
     InstRegs ir;
     if (KIND != PCBENV_SQUARE) fetch_instance(p, l.hdr->qcursor, e, lane, ir);
     bool rows_cleared = false;
-    if ((KIND == PCBENV_PIN || KIND == PCBENV_SPATIAL) && l.hdr->feat_gen == p.bind_gen &&
+    if ((KIND == PCBENV_PIN || KIND == PCBENV_SPATIAL) && !full && l.hdr->feat_gen == p.bind_gen &&
         (KIND == PCBENV_SPATIAL || p.C * p.mp <= H * WW * 64)) {
         u64 *rowbits = l.hf;
         if (KIND == PCBENV_PIN) {
@@ -43,22 +44,22 @@ template <int KIND, int WW> __device__ inline void reset_env(const DevParams &p,
                 const int q = lane + r * NT;
                 if (q < ir.np && q < p.P) {
                     const u64 w = ir.pin[r];
-                    const int row = (int)((w >> 24) & 0xFF) * p.mp + (int)((w >> 32) & PIN_ID_MASK);
-                    atomicOr((unsigned long long *)&rowbits[row >> 6], 1ull << (row & 63));
+                    const int prow = (int)((w >> 24) & 0xFF) * p.mp + (int)((w >> 32) & PIN_ID_MASK);
+                    atomicOr((unsigned long long *)&rowbits[prow >> 6], 1ull << (prow & 63));
                 }
             }
             lds_sync();
         }
         for (int q = lane; q < l.hdr->npins; q += NT) {
             const PinRec pr = l.pins[q];
-            const int row = KIND == PCBENV_SPATIAL ? (pr.id & PIN_ID_MASK) : pr.comp * p.mp + (pr.id & PIN_ID_MASK);
-            if (KIND == PCBENV_SPATIAL ? row < ir.np : (int)((rowbits[row >> 6] >> (row & 63)) & 1ull)) continue;
+            const int prow = KIND == PCBENV_SPATIAL ? (pr.id & PIN_ID_MASK) : pr.comp * p.mp + (pr.id & PIN_ID_MASK);
+            if (KIND == PCBENV_SPATIAL ? prow < ir.np : (int)((rowbits[prow >> 6] >> (prow & 63)) & 1ull)) continue;
             if (p.buf.all_pins_num_feature) {
-                double *f = p.buf.all_pins_num_feature + ((size_t)e * p.pinRows + row) * 4;
+                double *f = p.buf.all_pins_num_feature + ((size_t)row * p.pinRows + prow) * 4;
                 f[0] = 0.0; f[1] = 0.0; f[2] = 0.0; f[3] = 0.0;
             }
             if (p.buf.all_pins_cat_feature) {
-                double *f = p.buf.all_pins_cat_feature + ((size_t)e * p.pinRows + row) * p.catW;
+                double *f = p.buf.all_pins_cat_feature + ((size_t)row * p.pinRows + prow) * p.catW;
                 f[0] = 0.0; if (KIND == PCBENV_SPATIAL) f[1] = 0.0;
             }
         }
@@ -71,7 +72,7 @@ template <int KIND, int WW> __device__ inline void reset_env(const DevParams &p,
         if (lane < p.C) {
             const u64 w = ir.comp;
             CompRec cr; cr.h = (unsigned char)w; cr.w = (unsigned char)(w >> 8); cr.px = -1; cr.py = -1;
-            cr.pad[0] = cr.pad[1] = cr.pad[2] = cr.pad[3] = 0;
+            cr.o = 0; cr.pad[0] = cr.pad[1] = cr.pad[2] = 0;
             if (lane >= nc) { cr.h = 0; cr.w = 0; }
             l.comps[lane] = cr;
         }
@@ -135,114 +136,87 @@ template <int KIND, int WW> __device__ inline void reset_env(const DevParams &p,
     }
     lds_sync();
     STAMP(16);
-    mask_and_emit<KIND, WW>(p, l, e, lane, true, 0, H);
+    mask_and_emit<KIND, WW>(p, l, row, lane, true, 0, H);
     STAMP(17);
 
     if (KIND != PCBENV_SQUARE) {
         const int nc = l.hdr->ncomp, np = l.hdr->npins;
-        // all_components_feature (R:60-79, S:203-239): [h, w, -1, -1, area/(H*W), (spatial: pin ids, -1 pad)]; absent rows 0
-        // spatial scratch in the class-map zone (free until the next emit_pin_grid): pid[c][k] = id of the k-th pin
-        // of component c in self.pins order (0xFFFF = none), netmask[c][rel_x][rel_y] = nets with a pin on that cell
-        unsigned short *pid = (unsigned short *)l.cls;
-        unsigned *netmask = (unsigned *)(l.cls + ((p.C * p.mp * 2 + 3) & ~3));
         if (KIND == PCBENV_SPATIAL) {
-            for (int i = lane; i < p.C * p.mp; i += NT) { pid[i] = 0xFFFFu; netmask[i] = 0u; }
-            lds_sync();
+            // rank of every pin among the pins of its component (self.pins order), kept in the state block
             for (int q = lane; q < np; q += NT) {
-                const PinRec pr = l.pins[q];
+                const int comp = l.pins[q].comp;
                 int rank = 0;
                 #pragma unroll 4
-                for (int q2 = 0; q2 < np; q2++) rank += (q2 < q) & (l.pins[q2].comp == pr.comp);  // broadcast reads
-                pid[pr.comp * p.mp + rank] = (unsigned short)(pr.id & PIN_ID_MASK);
-                atomicOr(&netmask[(int)pr.comp * p.mp + pr.rel_x * p.mw + pr.rel_y], 1u << pr.net);
+                for (int q2 = 0; q2 < np; q2++) rank += (q2 < q) & (l.pins[q2].comp == comp);  // broadcast reads
+                l.rank[q] = (unsigned char)rank;
             }
-            lds_sync();
+            build_pin_tables(p, l, lane);  // pid / netmask scratch in the class-map zone (free until the next emit_pin_grid)
         }
-        // all_components_feature (R:60-79, S:203-239): [h, w, -1, -1, area/(H*W), (spatial: pin ids, -1 pad)]; absent rows 0
-        if (p.buf.all_components_feature) {
-            double *cf = p.buf.all_components_feature + (size_t)e * p.C * p.F;
-            for (int i = lane; i < p.C * p.F; i += NT) {
-                const int c = i / p.F, k = i - c * p.F;
-                double v = 0.0;
-                if (c < nc) {
-                    const CompRec cr = l.comps[c];
-                    if (k == 0) v = cr.h; else if (k == 1) v = cr.w; else if (k == 2 || k == 3) v = -1.0;
-                    else if (k == 4) v = (double)(cr.h * cr.w) / p.area;
-                    else {
-                        const unsigned id = KIND == PCBENV_SPATIAL ? pid[c * p.mp + k - 5] : 0xFFFFu;
-                        v = id == 0xFFFFu ? -1.0 : (double)id;
+        if (full) {
+            emit_features_full<KIND>(p, l, row, lane);
+        } else {
+            const PinTables t = pin_tables(p, l);
+            // all_components_feature (R:60-79, S:203-239): [h, w, -1, -1, area/(H*W), (spatial: pin ids, -1 pad)]; absent rows 0
+            if (p.buf.all_components_feature) {
+                double *cf = p.buf.all_components_feature + (size_t)row * p.C * p.F;
+                for (int i = lane; i < p.C * p.F; i += NT) {
+                    const int c = i / p.F, k = i - c * p.F;
+                    double v = 0.0;
+                    if (c < nc) {
+                        const CompRec cr = l.comps[c];
+                        if (k == 0) v = cr.h; else if (k == 1) v = cr.w; else if (k == 2 || k == 3) v = -1.0;
+                        else if (k == 4) v = (double)(cr.h * cr.w) / p.area;
+                        else {
+                            const unsigned id = KIND == PCBENV_SPATIAL ? t.pid[c * p.mp + k - 5] : 0xFFFFu;
+                            v = id == 0xFFFFu ? -1.0 : (double)id;
+                        }
                     }
+                    cf[i] = v;
                 }
-                cf[i] = v;
             }
-        }
-        STAMP(18);
-        if (p.buf.placement_mask) {
-            double *pm = p.buf.placement_mask + (size_t)e * p.C;
-            for (int c = lane; c < p.C; c += NT)
-                pm[c] = KIND == PCBENV_RECT ? 0.0 : (c == 0 ? 3.0 : (c < nc ? 1.0 : 0.0));
-        }
-        if (KIND == PCBENV_RECT && p.buf.component_mask) {
-            double *cm = p.buf.component_mask + (size_t)e * p.C;
-            for (int c = lane; c < p.C; c += NT) cm[c] = c < nc ? 1.0 : 0.0;
-        }
-        if (KIND == PCBENV_PIN || KIND == PCBENV_SPATIAL) {
-            if (!rows_cleared && p.buf.all_pins_num_feature) {
-                double *f = p.buf.all_pins_num_feature + (size_t)e * p.pinRows * 4;
-                for (int i = lane; i < p.pinRows * 4; i += NT) f[i] = 0.0;
+            STAMP(18);
+            if (p.buf.placement_mask) {
+                double *pm = p.buf.placement_mask + (size_t)row * p.C;
+                for (int c = lane; c < p.C; c += NT)
+                    pm[c] = KIND == PCBENV_RECT ? 0.0 : (c == 0 ? 3.0 : (c < nc ? 1.0 : 0.0));
             }
-            if (!rows_cleared && p.buf.all_pins_cat_feature) {
-                double *f = p.buf.all_pins_cat_feature + (size_t)e * p.pinRows * p.catW;
-                for (int i = lane; i < p.pinRows * p.catW; i += NT)
-                    f[i] = (KIND == PCBENV_SPATIAL && i >= (p.pinRows - 1) * p.catW) ? -1.0 : 0.0;  // S:1520
+            if (KIND == PCBENV_RECT && p.buf.component_mask) {
+                double *cm = p.buf.component_mask + (size_t)row * p.C;
+                for (int c = lane; c < p.C; c += NT) cm[c] = c < nc ? 1.0 : 0.0;
             }
-            if (lane == 0) l.hdr->feat_gen = p.bind_gen;
-            if (!rows_cleared) {  // first reset after a bind: the full zero fill above must land before the row writes
-                __syncthreads();
-                __threadfence_block();
-            }
-            for (int q = lane; q < np; q += NT) {
-                const PinRec pr = l.pins[q];
-                write_pin_num<KIND>(p, e, pr);
-                if (p.buf.all_pins_cat_feature) {
-                    if (KIND == PCBENV_SPATIAL) {
-                        double *f = p.buf.all_pins_cat_feature + ((size_t)e * p.pinRows + (pr.id & PIN_ID_MASK)) * 2;
-                        f[0] = pr.net; f[1] = pr.comp;
-                    } else if (!(pr.id & PIN_LOSER)) {
-                        p.buf.all_pins_cat_feature[(size_t)e * p.pinRows + pr.comp * p.mp + (pr.id & PIN_ID_MASK)] = pr.net;
+            if (KIND == PCBENV_PIN || KIND == PCBENV_SPATIAL) {
+                if (!rows_cleared && p.buf.all_pins_num_feature) {
+                    double *f = p.buf.all_pins_num_feature + (size_t)row * p.pinRows * 4;
+                    for (int i = lane; i < p.pinRows * 4; i += NT) f[i] = 0.0;
+                }
+                if (!rows_cleared && p.buf.all_pins_cat_feature) {
+                    double *f = p.buf.all_pins_cat_feature + (size_t)row * p.pinRows * p.catW;
+                    for (int i = lane; i < p.pinRows * p.catW; i += NT)
+                        f[i] = (KIND == PCBENV_SPATIAL && i >= (p.pinRows - 1) * p.catW) ? -1.0 : 0.0;  // S:1520
+                }
+                if (lane == 0) l.hdr->feat_gen = p.bind_gen;
+                if (!rows_cleared) {  // first reset after a bind: the full zero fill above must land before the row writes
+                    __syncthreads();
+                    __threadfence_block();
+                }
+                for (int q = lane; q < np; q += NT) {
+                    const PinRec pr = l.pins[q];
+                    write_pin_num<KIND>(p, row, pr);
+                    if (p.buf.all_pins_cat_feature) {
+                        if (KIND == PCBENV_SPATIAL) {
+                            double *f = p.buf.all_pins_cat_feature + ((size_t)row * p.pinRows + (pr.id & PIN_ID_MASK)) * 2;
+                            f[0] = pr.net; f[1] = pr.comp;
+                        } else if (!(pr.id & PIN_LOSER)) {
+                            p.buf.all_pins_cat_feature[(size_t)row * p.pinRows + pr.comp * p.mp + (pr.id & PIN_ID_MASK)] = pr.net;
+                        }
                     }
                 }
             }
         }
         STAMP(19);
         if (KIND == PCBENV_SPATIAL) {
-            if (p.buf.pin_grid) emit_zero(p.buf.pin_grid + (size_t)e * HW * p.K, (long long)HW * p.K, lane, p.stream_stores);  // S:1504
-            if (p.buf.component_grid) {  // S:1677-1697 draw_components (unrotated rel coords; channel 0 == 1)
-                const int cells = p.mh * p.mw, cgsz = cells * p.K, total = p.C * cgsz;
-                unsigned char *cg = p.buf.component_grid + (size_t)e * total;
-                // byte (cell, ch) = ch == 0 ? component exists : net ch-1 has a pin on the cell; each byte written once
-                if ((total & 15) == 0 && (((uintptr_t)cg) & 15) == 0) {
-                    const ObsDst d = obs_dst(cg, total);
-                    for (int c16 = lane; c16 < total / 16; c16 += NT) {
-                        const int bb = c16 * 16;
-                        int cell = bb / p.K, ch = bb - cell * p.K;
-                        u64 field = ((u64)netmask[cell] << 1) | (u64)(cell / cells < nc);  // bit ch = byte value of channel ch
-                        u64 lo = 0ull, hi = 0ull;
-                        #pragma unroll
-                        for (int k = 0; k < 16; k++) {
-                            const u64 bit = (field >> ch) & 1ull;
-                            if (k < 8) lo |= bit << (8 * k); else hi |= bit << (8 * (k - 8));
-                            if (++ch == p.K) { ch = 0; cell++; field = cell < p.C * cells ? (((u64)netmask[cell] << 1) | (u64)(cell / cells < nc)) : 0ull; }
-                        }
-                        STORE16_dyn(d, (unsigned)bb, make_uint4((unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)), p.stream_stores);
-                    }
-                } else {
-                    for (int i = lane; i < total; i += NT) {
-                        const int cell = i / p.K, ch = i - cell * p.K;
-                        cg[i] = (unsigned char)(ch == 0 ? (cell / cells < nc) : ((netmask[cell] >> (ch - 1)) & 1u));
-                    }
-                }
-            }
+            if (p.buf.pin_grid) emit_zero(p.buf.pin_grid + (size_t)row * HW * p.K, (long long)HW * p.K, lane, p.stream_stores);  // S:1504
+            emit_component_grid(p, l, row, lane);  // S:1677-1697 draw_components (unrotated rel coords; channel 0 == 1)
         }
     }
     lds_sync();
@@ -255,12 +229,13 @@ __global__ __launch_bounds__(64 * NW) void k_reset(DevParams p, const unsigned c
     if (mask && !mask[e]) return;
     load_state(smem, p, e, lane);  // cursor / episode survive; the old pins tell which feature rows to clear
     Lds l = carve(smem, p);
-    reset_env<KIND, WW>(p, l, e, lane);
+    const int row = out_row(p, p.slot, e);
+    reset_env<KIND, WW, true>(p, l, e, row, lane);
     if (lane == 0) {
         l.hdr->pre_action = 0u;  // the mask changed under any presampled action
-        p.buf.reward[e] = 0.0;
-        p.buf.done[e] = 0;
-        if (p.buf.info) { p.buf.info[2 * e] = nan(""); p.buf.info[2 * e + 1] = nan(""); }
+        p.buf.reward[row] = 0.0;
+        p.buf.done[row] = 0;
+        if (p.buf.info) { p.buf.info[2 * (size_t)row] = nan(""); p.buf.info[2 * (size_t)row + 1] = nan(""); }
     }
     store_state(smem, p, e, lane);
 }

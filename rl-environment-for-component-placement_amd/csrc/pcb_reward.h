@@ -24,42 +24,49 @@ __device__ inline bool is_intersect(double x1, double y1, double x2, double y2, 
 // ---- routes -------------------------------------------------------------------------------------
 // A route is kept as one segment slot per pin q (slots of net n are nstart[n]..nstart[n+1]-1, so slots are
 // net-major like the reference's route lists); act[q] = 1 if the slot carries a segment.
-struct SegView { double *X1, *Y1, *X2, *Y2, *D, *A, *DX, *DY, *cen; int *act, *nstart; unsigned *bbox; unsigned short *ns, *pairs; unsigned char *beam; };
-// compaction buffer of candidate (i, j) pairs: 1024 entries for a one-wavefront workgroup, 512 per wavefront for four
-#define PAIR_ENTRIES(NW) ((NW) == 1 ? 1024 : 2048)
-// [segments X1 Y1 X2 Y2 D | centroids | act nstart] then a zone used only by the pair count (A DX DY bbox ns pairs),
-// which the beam search -- finished before the count starts -- overlays with its per-net scratch.
-#define SEG_FIXED_BYTES(P) ((5 * (P) + 2 * PCBENV_MAX_NETS) * 8 + ((P) + PCBENV_MAX_NETS + 4) * 4)
-#define SEG_COUNT_BYTES(P, NW) (3 * (P) * 8 + (P) * 4 + (((P) + 1) & ~1) * 2 + PAIR_ENTRIES(NW) * 2)
+struct SegView { double *X1, *Y1, *X2, *Y2, *D, *A, *DX, *DY, *cen; int *act, *nstart, *nsum; unsigned *bbox; unsigned short *pairs; unsigned char *beam; };
+// compaction buffer of candidate (i, j) pairs, per wavefront: a dense batch is two candidates per lane (128), a
+// sweep step appends at most 4 * 64 to a partial batch (< 128), and what does not fill a batch is moved to the front
+#define PAIR_ENTRIES_PER_WAVE 384
+// [segments X1 Y1 X2 Y2 D | centroids | act nstart total nsum] then a zone used only by the pair count
+// (A DX DY bbox pairs), which the beam search -- finished before the count starts -- overlays with its per-net scratch.
+#define SEG_INTS(P) ((P) + (PCBENV_MAX_NETS + 1) + 3 + 2 * PCBENV_MAX_NETS)
+#define SEG_FIXED_BYTES(P) ((5 * (P) + 2 * PCBENV_MAX_NETS) * 8 + SEG_INTS(P) * 4)
+#define SEG_COUNT_BYTES(P, NW) (3 * (P) * 8 + (P) * 4 + PAIR_ENTRIES_PER_WAVE * 2 * (NW))
 #define SEG_LDS_BYTES(P, NW, beam) (((SEG_FIXED_BYTES(P) + 7) & ~7) + ((beam) > SEG_COUNT_BYTES(P, NW) ? (beam) : SEG_COUNT_BYTES(P, NW)))
 __device__ inline SegView seg_view(double *seg, int P) {
     SegView v;
     v.X1 = seg; v.Y1 = seg + P; v.X2 = seg + 2 * P; v.Y2 = seg + 3 * P; v.D = seg + 4 * P;
     v.cen = seg + 5 * P;                              // cx[MAX_NETS], cy[MAX_NETS]
     v.act = (int *)(v.cen + 2 * PCBENV_MAX_NETS);     // [P]
-    v.nstart = v.act + P;                             // [nnets + 1] (+ spare counter slot)
+    v.nstart = v.act + P;                             // [MAX_NETS + 1], then 3 spare words (nstart[MAX_NETS + 1] = pair counter)
+    v.nsum = v.nstart + PCBENV_MAX_NETS + 1 + 3;      // [2 * MAX_NETS] integer coordinate sums per net
     v.beam = (unsigned char *)seg + ((SEG_FIXED_BYTES(P) + 7) & ~7);
     v.A = (double *)v.beam; v.DX = v.A + P; v.DY = v.A + 2 * P;  // per segment: x1*y2 - y1*x2, x1 - x2, y1 - y2
     v.bbox = (unsigned *)(v.A + 3 * P);               // [P] integer extents (x_lo, x_hi, y_lo, y_hi), one byte each
-    v.ns = (unsigned short *)(v.bbox + P);            // [P] first slot of the slot's own net (= number of earlier-net slots)
-    v.pairs = v.ns + ((P + 1) & ~1);                  // [PAIR_ENTRIES] shared out among the wavefronts
+    v.pairs = (unsigned short *)(v.bbox + P);         // [PAIR_ENTRIES_PER_WAVE] per wavefront
     return v;
 }
 
-// net_pins offsets (self.pins is net-major) and S:1229-1241 get_centroid per net (exact integer sums, one division)
+// net_pins offsets (self.pins is net-major) and S:1229-1241 get_centroid per net: np.mean of an integer array =
+// (exact integer sum, as float64) / n -- the sums are gathered with LDS integer atomics (order-free because exact).
 __device__ inline void net_offsets_and_centroids(const SegView &v, const EnvHdr *hdr, const PinRec *pins, int lane) {
     const int np = hdr->npins, nn = hdr->nnets;
     lds_sync();  // the segment area aliases the class map of emit_pin_grid
-    for (int q = lane; q < np; q += NT)
-        if (q == 0 || pins[q].net != pins[q - 1].net) v.nstart[pins[q].net] = q;
+    for (int n = lane; n < 2 * PCBENV_MAX_NETS; n += NT) v.nsum[n] = 0;
+    lds_sync();
+    for (int q = lane; q < np; q += NT) {
+        const PinRec pr = pins[q];
+        if (q == 0 || pr.net != pins[q - 1].net) v.nstart[pr.net] = q;
+        atomicAdd(&v.nsum[pr.net], (int)pr.abs_x);
+        atomicAdd(&v.nsum[PCBENV_MAX_NETS + pr.net], (int)pr.abs_y);
+    }
     if (lane == 0) v.nstart[nn] = np;
     lds_sync();
     for (int n = lane; n < nn; n += NT) {
-        const int s = v.nstart[n], e = v.nstart[n + 1];
-        double sx = 0, sy = 0;
-        for (int q = s; q < e; q++) { sx += (double)pins[q].abs_x; sy += (double)pins[q].abs_y; }
-        v.cen[n] = sx / (double)(e - s);
-        v.cen[PCBENV_MAX_NETS + n] = sy / (double)(e - s);
+        const double cnt = (double)(v.nstart[n + 1] - v.nstart[n]);
+        v.cen[n] = (double)v.nsum[n] / cnt;
+        v.cen[PCBENV_MAX_NETS + n] = (double)v.nsum[PCBENV_MAX_NETS + n] / cnt;
     }
     lds_sync();
 }
@@ -114,7 +121,7 @@ __device__ inline bool extents_overlap(unsigned a, unsigned b) {  // branch-free
     return ((a & b & 0x80000000u) != 0) & (xl <= xh) & (yl <= yh);
 }
 
-// Full test on the n candidates a wavefront has collected, two per lane and step so that their LDS reads and
+// Full test on candidates [0, n) of a wavefront's buffer, two per lane and step so that their LDS reads and
 // divisions overlap.
 typedef __attribute__((address_space(3))) unsigned short lds_u16;  // keeps the buffer accesses ds_* instead of flat_*
 __device__ inline int count_candidates(const SegView &v, const volatile lds_u16 *buf, int n, int wl_lane) {
@@ -128,62 +135,69 @@ __device__ inline int count_candidates(const SegView &v, const volatile lds_u16 
     return cnt;
 }
 
-// S:629-651 find_num_intersection + S:704-722 find_wirelength over the slots.  The (segment, later-net segment)
-// pairs are first filtered by extent overlap, the survivors compacted into an LDS buffer and run through the full
-// test in dense batches (see count_finish).  The wirelength
-// is summed sequentially in route order (bit-exact with the reference's python float loop).
+// S:629-651 find_num_intersection + S:704-722 find_wirelength over the slots.
+// Slots are net-major, so the partners "segment of an earlier net" of the slots of net n are the slots
+// 0..nstart[n]-1: net n contributes the block nstart[n] x (its own slots) of pairs.  The blocks are swept one
+// after the other, 64 pairs at a time, the sweep steps dealt out to the wavefronts: every lane
+// of every sweep step holds one pair, whatever the shape of the block (the triangle of the old per-slot sweep left
+// half the lanes idle and cost one step per partner).  A pair is first tested on its packed integer extents; the
+// survivors of a step are appended to the wavefront's compaction buffer with a ballot, and the buffer goes through
+// the full float64 test in dense batches of 128.  The wirelength is summed sequentially in route order (bit-exact
+// with the reference's python float loop).
 // count_prepare reads the pins, count_finish only the segment zone.
-__device__ inline void count_prepare(const SegView &v, int np, const PinRec *pins, int lane) {
+__device__ inline void count_prepare(const SegView &v, int np, int lane) {
     int *total_cnt = v.nstart + PCBENV_MAX_NETS + 1;  // spare slot behind nstart[0..MAX_NETS]
     for (int q = lane; q < np; q += NT) {
         const double x1 = v.X1[q], y1 = v.Y1[q], x2 = v.X2[q], y2 = v.Y2[q];
         v.A[q] = x1 * y2 - y1 * x2; v.DX[q] = x1 - x2; v.DY[q] = y1 - y2;
         v.bbox[q] = v.act[q] ? pack_extents(x1, y1, x2, y2) : 0u;
-        v.ns[q] = (unsigned short)v.nstart[pins[q].net];
     }
     if (lane == 0) *total_cnt = 0;
     lds_sync();
 }
-__device__ inline void count_finish(const DevParams &p, const SegView &v, int np_, int lane, double *wirelength, int *nintersections) {
+__device__ inline void count_finish(const DevParams &p, const SegView &v, int np_, int nn_, int lane, double *wirelength, int *nintersections) {
     int *total_cnt = v.nstart + PCBENV_MAX_NETS + 1;
-    const int np = __builtin_amdgcn_readfirstlane(np_);
+    const int np = __builtin_amdgcn_readfirstlane(np_), nn = __builtin_amdgcn_readfirstlane(nn_);
     STAMP(12);
+    STAMP_ZERO(26); STAMP_ZERO(27); STAMP_ZERO(28); STAMP_ZERO(29);
     const int wl_lane = lane & 63, wave = lane >> 6, nwaves = NT / WAVE;
-    const int cap = PAIR_ENTRIES(nwaves) / nwaves;
-    volatile lds_u16 *buf = (volatile lds_u16 *)(v.pairs + wave * cap);  // wave-synchronous: written and read by different lanes
-    // Slots are net-major, so the partners "segment of an earlier net" of slot j are the slots i < ns[j].  The work
-    // is cut into 64 x 64 tiles (j chunk, i chunk <= j chunk) dealt out to the wavefronts.  In a tile lane j keeps
-    // its packed extents in a register and the wavefront sweeps the i chunk: one broadcast LDS word per step, no
-    // dependent reads; the survivors of a step are appended to the compaction buffer with a ballot.  That leaves the
-    // buffer i-major with ascending j, so a dense batch reads the i side as broadcasts and the j side from
-    // consecutive addresses.  The buffer is run through the full test whenever another step might not fit.
-    const int nchunk = (np + WAVE - 1) / WAVE, ntiles = nchunk * (nchunk + 1) / 2;
-    int cnt = 0, nbuf = 0;
-    for (int tile = wave; tile < ntiles; tile += nwaves) {  // wave-uniform
-        int jc = 0, ic = tile;
-        while (ic > jc) { ic -= jc + 1; jc++; }
-        const int j = WAVE * jc + wl_lane;
-        const unsigned bj = j < np ? v.bbox[j] : 0u;
-        const int lim = j < np ? (int)v.ns[j] : 0;
-        // ns grows with j, so the last slot of the chunk bounds the sweep; readfirstlane keeps the trip count in an SGPR
-        const int i0 = WAVE * ic;
-        const int i1 = __builtin_amdgcn_readfirstlane(min(i0 + WAVE, (int)v.ns[min(np - 1, WAVE * jc + WAVE - 1)]));
-        for (int ib = i0; ib < i1; ib += 4) {
-            unsigned bi[4];
-            #pragma unroll
-            for (int u = 0; u < 4; u++) bi[u] = v.bbox[min(ib + u, i1 - 1)];  // the four reads go out together
+    volatile lds_u16 *buf = (volatile lds_u16 *)(v.pairs + wave * PAIR_ENTRIES_PER_WAVE);  // wave-synchronous: written and read by different lanes
+    int cnt = 0, nbuf = 0, step = 0;
+    for (int n = 1; n < nn; n++) {  // wave-uniform; net 0 has no earlier net
+        const int s = __builtin_amdgcn_readfirstlane(v.nstart[n]), c = __builtin_amdgcn_readfirstlane(v.nstart[n + 1]) - s;
+        const int R = s * c;                         // pairs (i, j): i in [0, s) earlier-net slot, j in [s, s + c)
+        const unsigned magic = (65536u + (unsigned)c - 1u) / (unsigned)max(c, 1);  // r / c == (r * magic) >> 16 for r < 4160, c <= 16
+        // four 64-pair groups per sweep step: their LDS reads go out together and the loop overhead is paid once
+        for (int base = 0; base < R; base += 4 * WAVE, step++) {
+            if ((step & (nwaves - 1)) != wave) continue;  // nwaves is 1 or 4
+            unsigned bi[4], bj[4]; int pi[4], pj[4];
             #pragma unroll
             for (int u = 0; u < 4; u++) {
-                const int i = ib + u;
-                const bool pass = (i < i1) & (i < lim) & extents_overlap(bi[u], bj);
+                const int r = base + u * WAVE + wl_lane;
+                const bool in = r < R;
+                pi[u] = in ? (int)(((unsigned)r * magic) >> 16) : 0;
+                pj[u] = in ? s + (r - pi[u] * c) : 0;
+                bi[u] = v.bbox[pi[u]]; bj[u] = v.bbox[pj[u]];
+                if (!in) bi[u] = 0u;  // fails the "both slots carry a segment" bit
+            }
+            #pragma unroll
+            for (int u = 0; u < 4; u++) {  // at most 4 * 64 new entries: the buffer holds them next to a partial batch
+                const bool pass = extents_overlap(bi[u], bj[u]);
                 const u64 ball = __ballot(pass);
-                if (pass) buf[nbuf + __popcll(ball & ((1ull << wl_lane) - 1ull))] = (unsigned short)(i | (j << 8));
+                if (pass) buf[nbuf + __popcll(ball & ((1ull << wl_lane) - 1ull))] = (unsigned short)(pi[u] | (pj[u] << 8));
                 nbuf += __popcll(ball);
             }
-            if (nbuf > cap - 4 * WAVE) { cnt += count_candidates(v, buf, nbuf, wl_lane); nbuf = 0; }  // no room for another group
+            while (nbuf >= 2 * WAVE) {  // dense batches; the rest (< 128 entries) moves to the front
+                STAMP_T0();
+                cnt += count_candidates(v, buf, 2 * WAVE, wl_lane);
+                STAMP_ACC_SINCE(26, cnt); STAMP_ADD(27, 1); STAMP_ADD(28, 2 * WAVE);
+                nbuf -= 2 * WAVE;
+                for (int k = wl_lane; k < nbuf; k += WAVE) { const unsigned short rest = buf[2 * WAVE + k]; buf[k] = rest; }
+            }
         }
     }
     STAMP(13);
+    STAMP_ADD(28, nbuf); STAMP_ADD(29, step);
     cnt += count_candidates(v, buf, nbuf, wl_lane);
     STAMP(14);
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
@@ -212,9 +226,9 @@ __device__ inline void count_finish(const DevParams &p, const SegView &v, int np
 }
 __device__ inline void count_and_length(const DevParams &p, const SegView &v, const EnvHdr *hdr, const PinRec *pins, int lane,
                                         double *wirelength, int *nintersections) {
-    const int np = hdr->npins;
-    count_prepare(v, np, pins, lane);
-    count_finish(p, v, np, lane, wirelength, nintersections);
+    const int np = hdr->npins, nn = hdr->nnets;
+    count_prepare(v, np, lane);
+    count_finish(p, v, np, nn, lane, wirelength, nintersections);
 }
 
 __device__ inline void route_centroid(const DevParams &p, const EnvHdr *hdr, const PinRec *pins, double *seg,
@@ -224,9 +238,9 @@ __device__ inline void route_centroid(const DevParams &p, const EnvHdr *hdr, con
     STAMP(5);
     build_centroid_segments(v, hdr, pins, lane);
     STAMP(6);
-    count_prepare(v, hdr->npins, pins, lane);
+    count_prepare(v, hdr->npins, lane);
     STAMP(22);
-    count_finish(p, v, hdr->npins, lane, wirelength, nintersections);
+    count_finish(p, v, hdr->npins, hdr->nnets, lane, wirelength, nintersections);
     STAMP(8);
 }
 

@@ -192,7 +192,9 @@ extern "C" int pcbenv_create(const pcbenv_config *cfg, int device, pcbenv **out)
     d.offVm = d.offOcc + d.H * d.WW * 8;
     d.offComps = d.offVm + 2 * d.H * d.WW * 8;
     d.offPins = d.offComps + 8 * d.C;
-    d.stateStride = align16((long long)d.offPins + 8ll * d.P);
+    d.offRank = d.offPins + 8 * d.P;  // rank of each pin inside its component (spatial env)
+    d.stateStride = align16((long long)d.offRank + (c.kind == PCBENV_SPATIAL ? d.P : 0));
+    d.num_slots = 1; d.slot = 0;
     d.instStride = align16(pcbenv_instance_stride(&c));
     // LDS scratch behind the state mirror
     d.ldsHf = (int)d.stateStride;
@@ -233,8 +235,23 @@ extern "C" void pcbenv_destroy(pcbenv *env) {
     delete env;
 }
 
-extern "C" int pcbenv_bind_buffers(pcbenv *env, const pcbenv_buffers *b) {
+extern "C" int pcbenv_bind_buffers_slots(pcbenv *env, const pcbenv_buffers *b, int32_t num_slots);
+extern "C" int pcbenv_bind_buffers(pcbenv *env, const pcbenv_buffers *b) { return pcbenv_bind_buffers_slots(env, b, 1); }
+
+extern "C" int pcbenv_select_slot(pcbenv *env, int32_t slot) {
+    if (!env) return fail(0, PCBENV_EINVAL, "null handle");
+    if (slot < 0 || slot >= env->dp.num_slots) return fail(env, PCBENV_EINVAL, "slot out of range");
+    env->dp.slot = slot;
+    return PCBENV_OK;
+}
+
+extern "C" int pcbenv_bind_buffers_slots(pcbenv *env, const pcbenv_buffers *b, int32_t num_slots) {
     if (!env || !b) return fail(env, PCBENV_EINVAL, "null argument");
+    if (num_slots < 1 || num_slots > 4096) return fail(env, PCBENV_EINVAL, "num_slots must be in [1, 4096]");
+    if (num_slots > 1 && (env->cfg.flags & PCBENV_FLAG_INCREMENTAL_OBS))
+        return fail(env, PCBENV_EINVAL, "PCBENV_FLAG_INCREMENTAL_OBS needs the in-place layout (num_slots = 1)");
+    if ((long long)num_slots * env->dp.B > 0x7fffffffll / 8) return fail(env, PCBENV_ELIMIT, "num_slots * num_envs too large");
+    env->dp.num_slots = num_slots; env->dp.slot = 0;
     if (!b->reward || !b->done) return fail(env, PCBENV_EINVAL, "reward and done buffers are required");
     env->dp.buf = *b;
     int k = env->cfg.kind;
@@ -273,7 +290,8 @@ extern "C" int pcbenv_load_instances(pcbenv *env, const int32_t *env_ids, int32_
         int per_net[PCBENV_MAX_NETS] = {0};
         for (int q = 0; q < h[2]; q++) {
             const int net = pr[8 * q + 2], comp = pr[8 * q + 3], id = pr[8 * q + 4] | (pr[8 * q + 5] << 8);
-            if (comp >= h[0] || net >= h[1] || net < prev) return fail(env, PCBENV_EINVAL, "pin record out of range or not net-major");
+            if (comp >= h[0] || net >= h[1] || (net != prev && net != prev + 1) || (q == 0 && net != 0))
+                return fail(env, PCBENV_EINVAL, "pin record out of range, or the pins are not net-major with nets 0, 1, 2, ... in order");
             if (pr[8 * q] >= cr[8 * comp] || pr[8 * q + 1] >= cr[8 * comp + 1]) return fail(env, PCBENV_EINVAL, "pin outside its component");
             if (++per_net[net] > PCBENV_MAX_PINS_PER_NET) return fail(env, PCBENV_EINVAL, "too many pins in one net");
             if (spatial) {  // feature row = the global pin id: a permutation of 0..num_pins-1
@@ -284,6 +302,8 @@ extern "C" int pcbenv_load_instances(pcbenv *env, const int32_t *env_ids, int32_
             }
             prev = net;
         }
+        if (h[2] > 0 && prev != h[1] - 1) return fail(env, PCBENV_EINVAL, "every net 0..num_nets-1 must have at least one pin");
+        if (h[2] == 0 && h[1] != 0 && pin_kind) return fail(env, PCBENV_EINVAL, "nets without pins");
     }
     unsigned char *base = d.queue + (size_t)slot * d.B * d.instStride;
     if (!env_ids && src_stride == d.instStride) {
@@ -309,10 +329,12 @@ template <int KIND> static int launch_reset(pcbenv *env, const uint8_t *mask, hi
     return 0;
 }
 template <int KIND> static int launch_step(pcbenv *env, int *actions, int fmt, int sampled, u64 seed, u64 first_env,
-                                           u64 step_index, hipStream_t s) {
+                                           u64 step_index, int num_steps, hipStream_t s) {
     const DevParams &d = env->dp;
-#define LAUNCH_STEP_(WW_, NW_, RT_, ST_) hipLaunchKernelGGL((k_step<KIND, WW_, NW_, RT_, ST_>), dim3(d.B), dim3(64 * NW_), d.ldsBytes, s, d, actions, fmt, sampled, seed, first_env, step_index)
-#define LAUNCH_STEP(WW_, NW_, RT_) do { if (d.stream_stores) LAUNCH_STEP_(WW_, NW_, RT_, true); else LAUNCH_STEP_(WW_, NW_, RT_, false); } while (0)
+    // lean build (in-place layout, one transition, store policy compiled in) or the trajectory / rollout build
+    const bool traj = d.num_slots > 1 || num_steps > 1;
+#define LAUNCH_STEP_(WW_, NW_, RT_, ST_, TJ_) hipLaunchKernelGGL((k_step<KIND, WW_, NW_, RT_, ST_, TJ_>), dim3(d.B), dim3(64 * NW_), d.ldsBytes, s, d, actions, fmt, sampled, seed, first_env, step_index, num_steps)
+#define LAUNCH_STEP(WW_, NW_, RT_) do { if (traj) LAUNCH_STEP_(WW_, NW_, RT_, false, true); else if (d.stream_stores) LAUNCH_STEP_(WW_, NW_, RT_, true, false); else LAUNCH_STEP_(WW_, NW_, RT_, false, false); } while (0)
     constexpr bool PINK = (KIND == PCBENV_PIN || KIND == PCBENV_SPATIAL);
     const bool routes = PINK && env->cfg.reward_type != PCBENV_REWARD_CENTROID;
     if (routes) {
@@ -324,12 +346,12 @@ template <int KIND> static int launch_step(pcbenv *env, int *actions, int fmt, i
     }
     return 0;
 }
-static int dispatch_step(pcbenv *env, int *actions, int fmt, int sampled, u64 seed, u64 first_env, u64 step_index, hipStream_t s) {
+static int dispatch_step(pcbenv *env, int *actions, int fmt, int sampled, u64 seed, u64 first_env, u64 step_index, int num_steps, hipStream_t s) {
     switch (env->cfg.kind) {
-    case PCBENV_SQUARE: return launch_step<PCBENV_SQUARE>(env, actions, fmt, sampled, seed, first_env, step_index, s);
-    case PCBENV_RECT: return launch_step<PCBENV_RECT>(env, actions, fmt, sampled, seed, first_env, step_index, s);
-    case PCBENV_PIN: return launch_step<PCBENV_PIN>(env, actions, fmt, sampled, seed, first_env, step_index, s);
-    default: return launch_step<PCBENV_SPATIAL>(env, actions, fmt, sampled, seed, first_env, step_index, s);
+    case PCBENV_SQUARE: return launch_step<PCBENV_SQUARE>(env, actions, fmt, sampled, seed, first_env, step_index, num_steps, s);
+    case PCBENV_RECT: return launch_step<PCBENV_RECT>(env, actions, fmt, sampled, seed, first_env, step_index, num_steps, s);
+    case PCBENV_PIN: return launch_step<PCBENV_PIN>(env, actions, fmt, sampled, seed, first_env, step_index, num_steps, s);
+    default: return launch_step<PCBENV_SPATIAL>(env, actions, fmt, sampled, seed, first_env, step_index, num_steps, s);
     }
 }
 
@@ -369,7 +391,7 @@ extern "C" int pcbenv_step(pcbenv *env, const int32_t *actions_dev, int32_t fmt,
     DEVICE_GUARD(env);
     if (!actions_dev) return fail(env, PCBENV_EINVAL, "null actions");
     if (fmt != PCBENV_ACTION_TUPLE && fmt != PCBENV_ACTION_FLAT) return fail(env, PCBENV_EINVAL, "unknown action format");
-    dispatch_step(env, (int *)actions_dev, fmt, 0, 0, 0, 0, (hipStream_t)stream);
+    dispatch_step(env, (int *)actions_dev, fmt, 0, 0, 0, 0, 1, (hipStream_t)stream);
     HIP_TRY(env, hipGetLastError());
     return PCBENV_OK;
 }
@@ -381,7 +403,7 @@ extern "C" int pcbenv_step_sampled(pcbenv *env, int32_t *actions_out_dev, int32_
     DEVICE_GUARD(env);
     if (!actions_out_dev) return fail(env, PCBENV_EINVAL, "null actions");
     if (fmt != PCBENV_ACTION_TUPLE && fmt != PCBENV_ACTION_FLAT) return fail(env, PCBENV_EINVAL, "unknown action format");
-    dispatch_step(env, actions_out_dev, fmt, 1, seed, first_env_index, step_index, (hipStream_t)stream);
+    dispatch_step(env, actions_out_dev, fmt, 1, seed, first_env_index, step_index, 1, (hipStream_t)stream);
     HIP_TRY(env, hipGetLastError());
     return PCBENV_OK;
 }
@@ -430,9 +452,14 @@ extern "C" int pcbenv_rollout_sampled(pcbenv *env, int32_t *actions_out_dev, int
     DEVICE_GUARD(env);
     if (!actions_out_dev || num_steps < 0) return fail(env, PCBENV_EINVAL, "bad rollout arguments");
     if (fmt != PCBENV_ACTION_TUPLE && fmt != PCBENV_ACTION_FLAT) return fail(env, PCBENV_EINVAL, "unknown action format");
-    const size_t per_step = (size_t)env->dp.B * (fmt == PCBENV_ACTION_TUPLE ? 3 : 1);
-    for (int t = 0; t < num_steps; t++)
-        dispatch_step(env, actions_out_dev + per_step * (size_t)t, fmt, 1, seed, first_env_index, step_index0 + (uint64_t)t, (hipStream_t)stream);
+    if (num_steps == 0) return PCBENV_OK;
+    if (env->cfg.flags & PCBENV_FLAG_INCREMENTAL_OBS) {  // row-incremental tensors: one launch per step, as before
+        const size_t per_step = (size_t)env->dp.B * (fmt == PCBENV_ACTION_TUPLE ? 3 : 1);
+        for (int t = 0; t < num_steps; t++)
+            dispatch_step(env, actions_out_dev + per_step * (size_t)t, fmt, 1, seed, first_env_index, step_index0 + (uint64_t)t, 1, (hipStream_t)stream);
+    } else {
+        dispatch_step(env, actions_out_dev, fmt, 1, seed, first_env_index, step_index0, num_steps, (hipStream_t)stream);
+    }
     HIP_TRY(env, hipGetLastError());
     return PCBENV_OK;
 }

@@ -60,7 +60,10 @@ class BatchedPlacementEnv:
     def __init__(self, cfg: EnvConfig, num_envs: int, device="cuda:0", queue_depth: int = 1,
                  run_seed: int = 0, first_env_index: int = 0, incremental_obs: bool = False,
                  auto_reset: bool = False, threads_per_env: int = 0,
-                 mask_marginals: bool = False):
+                 mask_marginals: bool = False, num_slots: int = 1):
+        """num_slots > 1: trajectory layout -- every output tensor is allocated `[num_slots, B, ...]` (`self.traj`,
+        `self.traj_reward`, ...), `select_slot(s)` chooses the slot the next reset / step writes and `self.obs`,
+        `self.reward`, `self.done`, `self.info_raw` are views of that slot (pcbenv_bind_buffers_slots)."""
         cfg.validate()
         self.cfg, self.num_envs, self.queue_depth = cfg, int(num_envs), int(queue_depth)
         self.run_seed, self.first_env_index = int(run_seed), int(first_env_index)
@@ -82,32 +85,36 @@ class BatchedPlacementEnv:
         _lib.check(self._L.pcbenv_create(C.byref(self._ccfg), dev_index, C.byref(h)))
         self._h = h
         B = self.num_envs
+        S = self.num_slots = int(num_slots)
         with torch.cuda.device(self.device):
-            self.obs: Dict[str, torch.Tensor] = {
-                k: torch.zeros((B,) + shape, dtype=dt, device=self.device) for k, (shape, dt) in obs_spec(cfg).items()}
-            self.reward = torch.zeros(B, dtype=torch.float64, device=self.device)
-            self.done = torch.zeros(B, dtype=torch.uint8, device=self.device)
-            self.info_raw = torch.full((B, 2), float("nan"), dtype=torch.float64, device=self.device)
+            self.traj: Dict[str, torch.Tensor] = {
+                k: torch.zeros((S, B) + shape, dtype=dt, device=self.device) for k, (shape, dt) in obs_spec(cfg).items()}
+            self.traj_reward = torch.zeros((S, B), dtype=torch.float64, device=self.device)
+            self.traj_done = torch.zeros((S, B), dtype=torch.uint8, device=self.device)
+            self.traj_info = torch.full((S, B, 2), float("nan"), dtype=torch.float64, device=self.device)
             self._actions = torch.zeros((B, 3), dtype=torch.int32, device=self.device)
             O = cfg.num_orientations
             # marginals of action_mask for factorised policies (not reference observation keys)
-            self.mask_marginals = {"orientation": torch.zeros((B, O), dtype=torch.uint8, device=self.device),
-                                   "rows": torch.zeros((B, O, cfg.height), dtype=torch.uint8, device=self.device)} if mask_marginals else {}
+            self.traj_marginals = {"orientation": torch.zeros((S, B, O), dtype=torch.uint8, device=self.device),
+                                   "rows": torch.zeros((S, B, O, cfg.height), dtype=torch.uint8, device=self.device)} if mask_marginals else {}
         bufs = _lib.PcbenvBuffers()
         for name in _lib.BUFFER_FIELDS:
-            t = self.obs.get(name)
+            t = self.traj.get(name)
             if name == "reward":
-                t = self.reward
+                t = self.traj_reward
             elif name == "done":
-                t = self.done
+                t = self.traj_done
             elif name == "info":
-                t = self.info_raw if cfg.kind in (KIND_PIN, KIND_SPATIAL) else None
+                t = self.traj_info if cfg.kind in (KIND_PIN, KIND_SPATIAL) else None
             elif name == "mask_orientation":
-                t = self.mask_marginals.get("orientation")
+                t = self.traj_marginals.get("orientation")
             elif name == "mask_rows":
-                t = self.mask_marginals.get("rows")
+                t = self.traj_marginals.get("rows")
             setattr(bufs, name, t.data_ptr() if t is not None else None)
-        _lib.check(self._L.pcbenv_bind_buffers(self._h, C.byref(bufs)), self._h)
+        _lib.check(self._L.pcbenv_bind_buffers_slots(self._h, C.byref(bufs), S), self._h)
+        self.slot = -1
+        self.select_slot(0)
+        self._last_done = self.done  # `done` of the latest step (it may live in another slot than the selected one)
         self._streams: Optional[List[InstanceStream]] = None
         self._native = None
         torch.cuda.synchronize(self.device)
@@ -127,6 +134,18 @@ class BatchedPlacementEnv:
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def select_slot(self, slot: int):
+        """The slot of the `[num_slots, B, ...]` tensors the next reset / step writes; `obs`, `reward`, `done`,
+        `info_raw`, `mask_marginals` become views of it."""
+        slot = int(slot) % self.num_slots
+        if slot == self.slot:
+            return
+        _lib.check(self._L.pcbenv_select_slot(self._h, slot), self._h)
+        self.slot = slot
+        self.obs: Dict[str, torch.Tensor] = {k: v[slot] for k, v in self.traj.items()}
+        self.reward, self.done, self.info_raw = self.traj_reward[slot], self.traj_done[slot], self.traj_info[slot]
+        self.mask_marginals = {k: v[slot] for k, v in self.traj_marginals.items()}
 
     # -- instances --------------------------------------------------------------------------
     def load_instances(self, instances: Sequence[Instance], slot: int = 0, env_ids: Optional[Sequence[int]] = None):
@@ -201,7 +220,7 @@ class BatchedPlacementEnv:
 
     def reset_done(self) -> Dict[str, torch.Tensor]:
         """Explicit auto-reset: environments whose last step returned done take their next instance."""
-        _lib.check(self._L.pcbenv_reset(self._h, self.done.data_ptr(), self._stream()), self._h)
+        _lib.check(self._L.pcbenv_reset(self._h, self._last_done.data_ptr(), self._stream()), self._h)
         return self.obs
 
     def step(self, actions: torch.Tensor):
@@ -219,6 +238,7 @@ class BatchedPlacementEnv:
             a = a.contiguous()
         assert a.shape[0] == self.num_envs
         _lib.check(self._L.pcbenv_step(self._h, a.data_ptr(), fmt, self._stream()), self._h)
+        self._last_done = self.done
         return self.obs, self.reward, self.done, self.info
 
     @property
@@ -245,11 +265,13 @@ class BatchedPlacementEnv:
         _lib.check(self._L.pcbenv_step_sampled(
             self._h, out.data_ptr(), _lib.ACTION_FLAT if flat else _lib.ACTION_TUPLE, self.run_seed,
             self.first_env_index, int(step_index), self._stream()), self._h)
+        self._last_done = self.done
         return self.obs, self.reward, self.done, self.info, out
 
     def rollout_steps(self, step_index0: int, num_steps: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """`num_steps` fused sample+step launches issued from C in one call (use with auto_reset=True);
-        returns the actions taken, int32 [num_steps, B, 3]."""
+        """`num_steps` sample+step transitions in one persistent kernel launch (use with auto_reset=True): step t
+        writes slot `(self.slot + t) % num_slots`; returns the actions taken, int32 [num_steps, B, 3].  The selected
+        slot is left where it was -- `select_slot(self.slot + num_steps)` continues behind the rollout."""
         if out is None:
             out = torch.empty((num_steps, self.num_envs, 3), dtype=torch.int32, device=self.device)
         _lib.check(self._L.pcbenv_rollout_sampled(

@@ -72,14 +72,14 @@ def test_golden_episodes_on_gpu(name):
 
 
 def _oracle_rollout(cfg, B, episodes, queue_depth=2, p_bad=0.02, incremental=False, auto_reset=False, fused=False,
-                    threads=0, cpu_threads=1, stats=None, max_steps=400):
+                    threads=0, cpu_threads=1, stats=None, max_steps=400, num_slots=1):
     """Device-sampled legal actions (plus a few corrupted ones); every observation, reward, done, info of every step
     must equal the CPU oracle's.  Covers reset_done() and the instance queue.  cpu_threads > 1: the oracle steps and
     the whole-batch tensor comparison run under OpenMP (full-size batches).  stats: filled with counts of the
     terminal kinds seen."""
     from oracle import oracle as orc
     env = BatchedPlacementEnv(cfg, B, queue_depth=queue_depth, run_seed=3, incremental_obs=incremental,
-                              auto_reset=auto_reset, threads_per_env=threads)
+                              auto_reset=auto_reset, threads_per_env=threads, num_slots=num_slots)
     packed = env.generate_instances(verify=4) if cfg.kind != KIND_SQUARE else None
     ob = orc.OracleBatch(cfg, B)
     cursor = np.zeros(B, np.int64)
@@ -104,6 +104,8 @@ def _oracle_rollout(cfg, B, episodes, queue_depth=2, p_bad=0.02, incremental=Fal
     t = 0
     keys = list(env.obs.keys())
     while done_eps < episodes * B and t < max_steps:
+        if num_slots > 1:  # trajectory layout: step t lands in slot (t + 1) % num_slots, slot 0 took the reset
+            env.select_slot(t + 1)
         if fused:
             sampled = env.sample_actions(t).cpu().numpy()  # must equal what the fused launch draws
             o, r, d, _, a_dev = env.rollout_step(t)
@@ -433,6 +435,69 @@ def test_no_legal_cell_terminals_with_in_launch_reset(threads, incremental):
     _oracle_rollout(cfgp, 256, episodes=4, queue_depth=2, p_bad=0.0, incremental=incremental, auto_reset=True,
                     fused=True, threads=threads, cpu_threads=8, stats=stats, max_steps=40)
     assert stats["worst_case_terminals"] > 50, stats
+
+
+@pytest.mark.parametrize("name,mode", [("c2", "explicit"), ("c3", "explicit"), ("c4", "explicit"), ("c4", "fused"), ("c3", "fused"),
+                                       ("small_spatial", "explicit"), ("small_spatial", "fused"), ("small_pin", "fused"), ("c1", "fused")])
+def test_trajectory_slots_every_tensor(name, mode):
+    """[num_slots, B, ...] layout (pcbenv_bind_buffers_slots): every step lands in its own slot and must write every
+    tensor whole -- the float64 feature tensors that the in-place layout maintains row by row, component_grid
+    (with the rotation of placed components undone, Q4), the unchanged observation after an invalid action."""
+    cfg = {"small_spatial": EnvConfig.spatial(10, 10, 3, 4, 2, 4, 2, 4, 6, 1, 2, 4, 5, 2, "both", 2, 0.5),
+           "small_pin": EnvConfig.pin(10, 10, 3, 4, 2, 4, 2, 4, 6, 1, 2, 4, 5, 2, "centroid", 2, 0.5)}.get(name) or named_config(name)
+    fused = mode == "fused"
+    _oracle_rollout(cfg, 96, episodes=3, queue_depth=2, p_bad=0.0 if fused else 0.03, auto_reset=fused, fused=fused,
+                    num_slots=5, max_steps=60)
+
+
+@pytest.mark.parametrize("name,B,T,S", [("c3", 512, 40, 41), ("c4", 256, 36, 37), ("c2", 512, 20, 7), ("c5", 64, 40, 41),
+                                        ("small_spatial", 256, 30, 31), ("c1", 64, 12, 13)])
+def test_persistent_rollout_fills_the_trajectory(name, B, T, S):
+    """pcbenv_rollout_sampled = ONE launch for T steps with the state held in LDS: slot (1 + t) % S of every tensor, the
+    recorded actions, rewards, dones and infos against the oracle stepping the same actions.  (S < T: the slots wrap.)"""
+    from oracle import oracle as orc
+    cfg = EnvConfig.spatial(10, 10, 3, 4, 2, 4, 2, 4, 6, 1, 2, 4, 5, 2, "both", 2, 0.5) if name == "small_spatial" else named_config(name)
+    Q = 8
+    env = BatchedPlacementEnv(cfg, B, queue_depth=Q, run_seed=11, auto_reset=True, num_slots=S)
+    packed = env.generate_instances(verify=4) if cfg.kind != KIND_SQUARE else None
+    ob = orc.OracleBatch(cfg, B)
+    cursor = np.zeros(B, np.int64)
+
+    def oracle_reset(mask):
+        if cfg.kind == KIND_SQUARE:
+            for i in np.flatnonzero(mask):
+                ob.env(i).reset()
+            return
+        ob.reset_packed(np.stack([packed[cursor[i] % Q][i] for i in range(B)]), mask.astype(np.uint8), 8)
+        cursor[mask.astype(bool)] += 1
+
+    env.reset()                       # slot 0
+    oracle_reset(np.ones(B, np.uint8))
+    env.select_slot(1)
+    acts = env.rollout_steps(0, T).cpu().numpy()
+    traj = {k: v.cpu().numpy() for k, v in env.traj.items()}
+    rew, done, info = env.traj_reward.cpu().numpy(), env.traj_done.cpu().numpy(), env.traj_info.cpu().numpy()
+    single = BatchedPlacementEnv(cfg, B, queue_depth=Q, run_seed=11, auto_reset=True)  # the same draws, one launch per step
+    if packed is not None:
+        for s_, pk in enumerate(packed):
+            single.load_packed(pk, slot=s_)
+    single.reset()
+    for t in range(T):
+        a1 = single.rollout_step(t)[4].cpu().numpy()
+        assert np.array_equal(a1, acts[t]), t
+        rr, dd, ii = ob.step(acts[t], 8)
+        oracle_reset(dd)
+        if t + S < T:
+            continue                  # this slot has been overwritten by a later step
+        s_ = (1 + t) % S
+        assert np.array_equal(done[s_], dd), t
+        assert _same_bits(rew[s_], rr), t
+        if cfg.kind in (KIND_PIN, KIND_SPATIAL):
+            has = dd.astype(bool)
+            assert _same_bits(info[s_][has], ii[has]) and np.isnan(info[s_][~has]).all(), t
+        for k in traj:
+            assert ob.first_mismatch(k, traj[k][s_], 8) < 0, (t, k)
+    env.close(); single.close()
 
 
 def test_flat_actions_equal_tuple_actions():

@@ -46,7 +46,13 @@ def report(title, s, done):
         if len(rows):
             print(f"  {label}: total {int(np.median(rows[:, 11] - rows[:, 0]))} cycles")
             for n, x, y in table:
+                if (rows[:, x] == 0).all() or (rows[:, y] == 0).all():
+                    continue  # a phase this configuration does not run (stamp never written)
                 print(f"    {n:28s} {int(np.median(rows[:, y] - rows[:, x])):7d}")
+            if label == "terminal" and rows[:, 28].any():
+                print(f"    pair count detail: sweep steps {int(np.median(rows[:, 29]))}, candidates after the extent filter "
+                      f"{int(np.median(rows[:, 28]))}, in-sweep dense batches {int(np.median(rows[:, 27]))} taking "
+                      f"{int(np.median(rows[:, 26]))} cycles")
 
 
 for stagger in (False, True):

@@ -212,6 +212,24 @@ void pcbenv_instgen_destroy(pcbenv_instgen *gen);
 int pcbenv_instgen_next(pcbenv_instgen *gen, void *record_out);
 int pcbenv_instgen_next_batch(pcbenv_instgen *const *streams, int32_t n, void *records_out, int32_t threads);
 
+/* On-device instance generator: the same streams as pcbenv_instgen_* (stream seeds_host[i] < 2^32 for environment i:
+ * what the reference draws after `np.random.seed(s); random.seed(s)`), generated by a kernel on a stream of the
+ * library's own, one lane per environment, straight into the instance queue -- so that EVERY reset takes a fresh
+ * instance, as the reference's reset() does (..._spatial.py:1487-1549), at the rate the step kernels consume them.
+ * Enable once, before or after the first reset; from then on the library owns the queue (pcbenv_load_instances is
+ * refused): every pcbenv_reset / pcbenv_step* / pcbenv_rollout_sampled first makes the caller's stream wait (an
+ * event wait on the device, never a host synchronisation) for a fill whose records cover whatever that launch can
+ * consume -- one record per environment for a reset or an auto-reset step, num_steps for a rollout, which must not
+ * exceed queue_depth -- and starts the next fill early enough to overlap the following launches.  A queue of
+ * 2-4x the records one launch can consume keeps the generator off the critical path (queue_depth <= 256).
+ * pcbenv_instgen_device_status brings the queue fully up to date (queue_depth records ahead of every cursor),
+ * synchronises, and reports 0 unless a reset ever found its record missing (bit 0; it never should) or a stream hit
+ * a draw the reference itself fails on / this library does not support (bit 1).  pcbenv_get_instances copies one queue slot (num_envs packed
+ * records) to the host, e.g. to replay an episode on the CPU. */
+int pcbenv_instgen_device_enable(pcbenv *env, const uint32_t *seeds_host, void *stream);
+int pcbenv_instgen_device_status(pcbenv *env, uint32_t *errors_out, void *stream);
+int pcbenv_get_instances(pcbenv *env, int32_t slot, void *host_dst, void *stream);
+
 /* Smallest and largest number of resets any environment has performed so far (= queue cursors; the next reset of
  * an environment with cursor c reads slot c % queue_depth).  A slot whose episode index is below *min_out has been
  * consumed by every environment and may be refilled.  Synchronises with `stream`. */

@@ -36,7 +36,22 @@ struct DevParams {
     // outputs into `slot` (the persistent rollout kernel: one slot per step).  With num_slots > 1 nothing may rely on
     // what an earlier step left in the destination, so the float64 feature tensors are written whole every step.
     int num_slots, slot;
+    // on-device instance generator (pcb_geninst.h), null when the host feeds the queue: records generated so far per
+    // environment, and a sticky error word a reset raises if it ever finds its record missing (it never should:
+    // the host-side bookkeeping of pcbenv_kernels.hip orders every fill before the launches that can consume it)
+    unsigned *gen_produced, *gen_errors;
+    // Queue cursor of every environment, published with agent-scope (write-through) stores at each reset.  The copy
+    // in the state block is written back lazily and only ever re-read on the environment's own XCD; a kernel on
+    // another stream (k_gen_fill) may run on any XCD, whose L2 is not coherent with the writer's.
+    unsigned *cursor_pub;
 };
+// Loads of data another stream's kernel (or a DMA) has written since this XCD last read the same addresses: instance
+// records and the generator's counters.  Agent-scope loads (`sc1`) are served coherently; a plain load may hit a
+// stale clean line in this XCD's L2.
+__device__ inline u64 load_agent(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline unsigned load_agent(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline int load_agent(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline void store_agent(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // In-kernel stamps (cdna_hip_programming.md §7): only in a separate diagnostic build, written to a buffer nothing
 // else reads; `PCBENV_STAMPS=1` in the environment allocates it, tools/kernel_stamps.py prints the phase profile.
 #ifdef PCBENV_STAMPS

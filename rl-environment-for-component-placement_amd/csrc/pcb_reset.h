@@ -14,10 +14,10 @@ __device__ inline void fetch_instance(const DevParams &p, unsigned qcursor, int 
     const unsigned char *rec = p.queue + ((size_t)slot * p.B + e) * p.instStride;
     const int *ih = (const int *)rec;
     const u64 *crec = (const u64 *)(rec + 16), *prec = crec + p.C;  // 8-byte records, one load each
-    ir.nc = ih[0]; ir.nn = ih[1]; ir.np = ih[2];
-    ir.comp = lane < p.C ? crec[lane] : 0ull;
+    ir.nc = load_agent(ih); ir.nn = load_agent(ih + 1); ir.np = load_agent(ih + 2);
+    ir.comp = lane < p.C ? load_agent(crec + lane) : 0ull;
     #pragma unroll
-    for (int r = 0; r < 4; r++) { const int q = lane + r * NT; ir.pin[r] = q < p.P ? prec[q] : 0ull; }
+    for (int r = 0; r < 4; r++) { const int q = lane + r * NT; ir.pin[r] = q < p.P ? load_agent(prec + q) : 0ull; }
 }
 
 template <int KIND, int WW, bool TRAJ> __device__ inline void reset_env(const DevParams &p, Lds &l, int e, int row, int lane) {
@@ -31,7 +31,10 @@ template <int KIND, int WW, bool TRAJ> __device__ inline void reset_env(const De
     // no ordering wait between the clear and the later row writes): spatial rows are the pin ids 0..np-1; the pin
     // env's rows [component, pin_id] go through a membership bit map in the fold scratch.
     InstRegs ir;
-    if (KIND != PCBENV_SQUARE) fetch_instance(p, l.hdr->qcursor, e, lane, ir);
+    if (KIND != PCBENV_SQUARE) {
+        fetch_instance(p, l.hdr->qcursor, e, lane, ir);
+        if (p.gen_produced && lane == 0 && load_agent(p.gen_produced + e) <= l.hdr->qcursor) atomicOr(p.gen_errors, 1u);
+    }
     bool rows_cleared = false;
     if ((KIND == PCBENV_PIN || KIND == PCBENV_SPATIAL) && !full && l.hdr->feat_gen == p.bind_gen &&
         (KIND == PCBENV_SPATIAL || p.C * p.mp <= H * WW * 64)) {
@@ -90,6 +93,7 @@ template <int KIND, int WW, bool TRAJ> __device__ inline void reset_env(const De
         if (lane == 0) {
             l.hdr->ncomp = (short)nc; l.hdr->nnets = (short)nn; l.hdr->npins = (short)np; l.hdr->cur = 0;
             l.hdr->qcursor += 1; l.hdr->episode += 1;
+            store_agent(p.cursor_pub + e, l.hdr->qcursor);
         }
         lds_sync();
         if (KIND == PCBENV_PIN && lane < WAVE) {

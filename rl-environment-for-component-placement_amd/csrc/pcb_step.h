@@ -213,7 +213,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(TRAJ ? 4 : 7, 8))) __launch_bounds
 __global__ __launch_bounds__(256) void k_cursor_range(DevParams p, unsigned *out) {
     unsigned lo = 0xFFFFFFFFu, hi = 0u;
     for (int e = threadIdx.x; e < p.B; e += 256) {
-        const unsigned c = ((const EnvHdr *)(p.state + (size_t)e * p.stateStride))->qcursor;
+        const unsigned c = load_agent(p.cursor_pub + e);  // not the state block: that copy is only coherent on its own XCD
         lo = min(lo, c); hi = max(hi, c);
     }
     for (int o = 32; o > 0; o >>= 1) { lo = min(lo, (unsigned)__shfl_xor((int)lo, o)); hi = max(hi, (unsigned)__shfl_xor((int)hi, o)); }

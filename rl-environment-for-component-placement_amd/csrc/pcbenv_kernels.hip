@@ -22,8 +22,11 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <vector>
+
 #include "pcbenv.h"
 #include "pcb_step.h"  // -> pcb_reset.h -> pcb_sampler.h -> pcb_observe.h -> pcb_beam.h -> pcb_reward.h -> pcb_device.h
+#include "pcb_geninst.h"
 
 // ==============================================================================================
 // host side: the C ABI (include/pcbenv.h)
@@ -35,7 +38,14 @@ struct pcbenv {
     bool bound;
     int threads;  // workgroup size (threads per environment)
     unsigned *scratch;  // 16 bytes of device memory for small read-backs
-    unsigned loaded_slots;  // bit s = slot s loaded for all environments at least once
+    unsigned long long loaded_slots[4];  // bit s = slot s loaded for all environments at least once
+    // on-device instance generator (pcbenv_instgen_device_enable): side stream + the bookkeeping that guarantees a
+    // record is complete before any launch can consume it (see gen_before_launch)
+    bool gen_on, gen_outstanding;
+    GenParams gp;
+    hipStream_t gen_stream;
+    hipEvent_t ev_snap, ev_fill;
+    long long since_waited, since_outstanding;
     char err[256];
 };
 
@@ -116,7 +126,7 @@ static int validate(const pcbenv_config *c) {
     // limits of this implementation
     if (c->height < 1 || c->width < 1 || c->height > PCBENV_MAX_SIDE || c->width > PCBENV_MAX_SIDE)
         return fail(0, PCBENV_ELIMIT, "grid side must be in [1, 128]");
-    if (c->queue_depth < 1 || c->queue_depth > 32) return fail(0, PCBENV_ELIMIT, "queue_depth must be in [1, 32]");
+    if (c->queue_depth < 1 || c->queue_depth > 256) return fail(0, PCBENV_ELIMIT, "queue_depth must be in [1, 256]");
     if (c->kind != PCBENV_SQUARE) {
         int side = c->max_component_h > c->max_component_w ? c->max_component_h : c->max_component_w;
         int shorter = c->height < c->width ? c->height : c->width;
@@ -211,7 +221,8 @@ extern "C" int pcbenv_create(const pcbenv_config *cfg, int device, pcbenv **out)
     DeviceGuard guard_(device);
     if (!guard_.ok) { int r = fail(0, PCBENV_EHIP, "hipSetDevice failed (no such device?)"); delete env; return r; }
     size_t sbytes = (size_t)d.stateStride * d.B, qbytes = (size_t)d.instStride * d.B * d.Q;
-    if (hipMalloc((void **)&d.state, sbytes) != hipSuccess || hipMalloc((void **)&d.queue, qbytes ? qbytes : 16) != hipSuccess ) {
+    if (hipMalloc((void **)&d.state, sbytes) != hipSuccess || hipMalloc((void **)&d.queue, qbytes ? qbytes : 16) != hipSuccess ||
+        hipMalloc((void **)&d.cursor_pub, 4 * (size_t)d.B) != hipSuccess) {
         int r = fail(0, PCBENV_EHIP, "hipMalloc failed");
         pcbenv_destroy(env);
         return r;
@@ -221,6 +232,7 @@ extern "C" int pcbenv_create(const pcbenv_config *cfg, int device, pcbenv **out)
 #endif
     hipMemset(d.state, 0, sbytes);
     hipMemset(d.queue, 0, qbytes ? qbytes : 16);
+    hipMemset(d.cursor_pub, 0, 4 * (size_t)d.B);
     hipDeviceSynchronize();
     *out = env;
     return PCBENV_OK;
@@ -229,8 +241,16 @@ extern "C" int pcbenv_create(const pcbenv_config *cfg, int device, pcbenv **out)
 extern "C" void pcbenv_destroy(pcbenv *env) {
     if (!env) return;
     DeviceGuard guard_(env->device);
+    if (env->gen_on) {
+        hipStreamSynchronize(env->gen_stream);
+        hipEventDestroy(env->ev_snap); hipEventDestroy(env->ev_fill);
+        hipStreamDestroy(env->gen_stream);
+        if (env->gp.gen) hipFree(env->gp.gen);
+        if (env->gp.produced) hipFree(env->gp.produced);
+    }
     if (env->dp.state) hipFree(env->dp.state);
     if (env->dp.queue) hipFree(env->dp.queue);
+    if (env->dp.cursor_pub) hipFree(env->dp.cursor_pub);
     if (env->scratch) hipFree(env->scratch);
     delete env;
 }
@@ -316,8 +336,8 @@ extern "C" int pcbenv_load_instances(pcbenv *env, const int32_t *env_ids, int32_
         }
     }
     HIP_TRY(env, hipStreamSynchronize(s));
-    if (!env_ids && n == d.B) env->loaded_slots |= 1u << slot;
-    else if (slot == 0 && env->loaded_slots == 0) env->loaded_slots |= 0;  // partial loads: caller's responsibility
+    if (env->gen_on) return fail(env, PCBENV_ESTATE, "the on-device generator owns the queue (pcbenv_instgen_device_enable)");
+    if (!env_ids && n == d.B) env->loaded_slots[slot >> 6] |= 1ull << (slot & 63);  // partial loads: caller's responsibility
     return PCBENV_OK;
 }
 
@@ -362,6 +382,8 @@ static int pre_launch(pcbenv *env) {
 }
 
 static int check_queue(pcbenv *env);
+static int gen_before_launch(pcbenv *env, int n, hipStream_t main);
+static void gen_after_launch(pcbenv *env, int n, hipStream_t main);
 extern "C" int pcbenv_reset(pcbenv *env, const uint8_t *mask_dev, void *stream) {
     int rc = pre_launch(env);
     if (rc) return rc;
@@ -369,6 +391,8 @@ extern "C" int pcbenv_reset(pcbenv *env, const uint8_t *mask_dev, void *stream) 
     rc = check_queue(env);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
+    rc = gen_before_launch(env, 1, s);
+    if (rc) return rc;
     switch (env->cfg.kind) {
     case PCBENV_SQUARE: launch_reset<PCBENV_SQUARE>(env, mask_dev, s); break;
     case PCBENV_RECT: launch_reset<PCBENV_RECT>(env, mask_dev, s); break;
@@ -376,12 +400,126 @@ extern "C" int pcbenv_reset(pcbenv *env, const uint8_t *mask_dev, void *stream) 
     default: launch_reset<PCBENV_SPATIAL>(env, mask_dev, s); break;
     }
     HIP_TRY(env, hipGetLastError());
+    gen_after_launch(env, 1, s);
     return PCBENV_OK;
 }
 
 static int check_queue(pcbenv *env) {
-    if (env->cfg.kind != PCBENV_SQUARE && env->loaded_slots != (env->dp.Q >= 32 ? ~0u : ((1u << env->dp.Q) - 1u)))
-        return fail(env, PCBENV_ESTATE, "every queue slot must be loaded (pcbenv_load_instances for all environments) first");
+    if (env->cfg.kind == PCBENV_SQUARE || env->gen_on) return PCBENV_OK;
+    for (int s = 0; s < env->dp.Q; s++)
+        if (!(env->loaded_slots[s >> 6] >> (s & 63) & 1ull))
+            return fail(env, PCBENV_ESTATE, "every queue slot must be loaded (pcbenv_load_instances for all environments) first");
+    return PCBENV_OK;
+}
+
+// ---- on-device instance generator: host protocol ------------------------------------------------------------
+// k_gen_fill runs on env->gen_stream, ordered after everything enqueued on the caller's stream at its snapshot
+// (ev_snap): when it has completed, every environment holds queue_depth records ahead of the cursor it had at the
+// snapshot.  A launch may consume at most n records per environment (one per reset, one per step with
+// PCBENV_FLAG_AUTO_RESET, num_steps per rollout), so a launch is safe as long as the launches since the snapshot of
+// the last fill the caller's stream has waited for add up to at most queue_depth; `since_waited` keeps that sum.
+// Fills are started early (a quarter of the queue consumed at worst) and waited for late, so they overlap the step
+// kernels; the wait is a stream-side event wait, never a host synchronisation.
+static void gen_start_fill(pcbenv *env, hipStream_t main) {
+    hipEventRecord(env->ev_snap, main);
+    hipStreamWaitEvent(env->gen_stream, env->ev_snap, 0);
+    hipLaunchKernelGGL(k_gen_fill, dim3((env->dp.B + WAVE - 1) / WAVE), dim3(WAVE), 0, env->gen_stream, env->gp);
+    hipEventRecord(env->ev_fill, env->gen_stream);
+    env->gen_outstanding = true;
+    env->since_outstanding = 0;
+}
+static int gen_before_launch(pcbenv *env, int n, hipStream_t main) {
+    if (!env->gen_on) return PCBENV_OK;
+    const long long Q = env->dp.Q;
+    if (n > Q) return fail(env, PCBENV_ELIMIT, "this launch may consume more instances per environment than queue_depth holds");
+    if (env->since_waited + n > Q) {
+        if (!env->gen_outstanding) gen_start_fill(env, main);
+        hipStreamWaitEvent(main, env->ev_fill, 0);
+        env->since_waited = env->since_outstanding;
+        env->gen_outstanding = false;
+        if (env->since_waited + n > Q) {  // that fill was snapshotted too long ago for this launch: one more, in stream order
+            gen_start_fill(env, main);
+            hipStreamWaitEvent(main, env->ev_fill, 0);
+            env->since_waited = 0;
+            env->gen_outstanding = false;
+        }
+    }
+    return PCBENV_OK;
+}
+static void gen_after_launch(pcbenv *env, int n, hipStream_t main) {
+    if (!env->gen_on) return;
+    env->since_waited += n;
+    if (env->gen_outstanding) env->since_outstanding += n;
+    else if (env->since_waited * 4 >= env->dp.Q) gen_start_fill(env, main);
+}
+
+extern "C" int pcbenv_instgen_device_enable(pcbenv *env, const uint32_t *seeds_host, void *stream) {
+    if (!env || !seeds_host) return fail(env, PCBENV_EINVAL, "null argument");
+    if (env->cfg.kind == PCBENV_SQUARE) return fail(env, PCBENV_EINVAL, "the square environment has no instances");
+    if (env->gen_on) return fail(env, PCBENV_ESTATE, "the on-device generator is already enabled");
+    DEVICE_GUARD(env);
+    const DevParams &d = env->dp;
+    const pcbenv_config &c = env->cfg;
+    GenParams &g = env->gp;
+    g.kind = c.kind; g.C = d.C; g.P = d.P; g.Q = d.Q; g.B = d.B;
+    g.min_comp = c.min_num_components; g.max_comp = c.max_num_components;
+    g.min_h = c.min_component_h; g.max_h = c.max_component_h; g.min_w = c.min_component_w; g.max_w = c.max_component_w;
+    g.min_nets = c.min_num_nets; g.max_nets = c.max_num_nets; g.min_ppn = c.min_num_pins_per_net; g.max_ppn = c.max_num_pins_per_net;
+    g.net_distribution = c.net_distribution; g.pin_spread = c.pin_spread;  // clipped at create like the reference does
+    g.instStride = d.instStride; g.queue = d.queue; g.cursor_pub = d.cursor_pub;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned *seeds_dev = 0;
+    HIP_TRY(env, hipMalloc((void **)&g.gen, sizeof(GenState) * (size_t)d.B));
+    HIP_TRY(env, hipMalloc((void **)&g.produced, 4 * (size_t)d.B + 4));
+    HIP_TRY(env, hipMalloc((void **)&seeds_dev, 4 * (size_t)d.B));
+    HIP_TRY(env, hipMemcpyAsync(seeds_dev, seeds_host, 4 * (size_t)d.B, hipMemcpyHostToDevice, s));
+    HIP_TRY(env, hipStreamCreateWithFlags(&env->gen_stream, hipStreamNonBlocking));
+    HIP_TRY(env, hipEventCreateWithFlags(&env->ev_snap, hipEventDisableTiming));
+    HIP_TRY(env, hipEventCreateWithFlags(&env->ev_fill, hipEventDisableTiming));
+    const dim3 grid((d.B + WAVE - 1) / WAVE);
+    hipLaunchKernelGGL(k_gen_seed, grid, dim3(WAVE), 0, s, g, seeds_dev);
+    hipLaunchKernelGGL(k_gen_fill, grid, dim3(WAVE), 0, s, g);  // the whole queue, before anything can consume it
+    HIP_TRY(env, hipGetLastError());
+    HIP_TRY(env, hipStreamSynchronize(s));
+    hipFree(seeds_dev);
+    env->dp.gen_produced = g.produced;
+    env->dp.gen_errors = g.produced + d.B;  // one word behind the counters
+    HIP_TRY(env, hipMemsetAsync(env->dp.gen_errors, 0, 4, s));
+    env->gen_on = true; env->gen_outstanding = false;
+    env->since_waited = 0; env->since_outstanding = 0;
+    return PCBENV_OK;
+}
+
+extern "C" int pcbenv_instgen_device_status(pcbenv *env, uint32_t *errors_out, void *stream) {
+    if (!env || !errors_out) return fail(env, PCBENV_EINVAL, "null argument");
+    if (!env->gen_on) return fail(env, PCBENV_ESTATE, "the on-device generator is not enabled");
+    DEVICE_GUARD(env);
+    // bring the queue fully up to date (queue_depth records ahead of every cursor as of now) and wait for it
+    gen_start_fill(env, (hipStream_t)stream);
+    HIP_TRY(env, hipStreamSynchronize(env->gen_stream));
+    env->gen_outstanding = false; env->since_waited = 0; env->since_outstanding = 0;
+    unsigned err = 0;
+    HIP_TRY(env, hipMemcpyAsync(&err, env->dp.gen_errors, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(env, hipStreamSynchronize((hipStream_t)stream));
+    std::vector<int> status((size_t)env->dp.B);  // first failing record of any stream (the reference raises there)
+    HIP_TRY(env, hipMemcpy2D(status.data(), 4, &env->gp.gen->status, sizeof(GenState), 4, (size_t)env->dp.B, hipMemcpyDeviceToHost));
+    for (int i = 0; i < env->dp.B; i++) if (status[(size_t)i] != 0) { err |= 2u; break; }
+    *errors_out = err;
+    return PCBENV_OK;
+}
+
+extern "C" int pcbenv_get_instances(pcbenv *env, int32_t slot, void *host_dst, void *stream) {
+    if (!env || !host_dst) return fail(env, PCBENV_EINVAL, "null argument");
+    if (slot < 0 || slot >= env->dp.Q) return fail(env, PCBENV_EINVAL, "slot out of range");
+    DEVICE_GUARD(env);
+    const DevParams &d = env->dp;
+    const long long dst_stride = pcbenv_instance_stride(&env->cfg);
+    // the copy runs on the stream that last wrote the queue (the generator's, if it is on): in order behind its kernels
+    hipStream_t s = env->gen_on ? env->gen_stream : (hipStream_t)stream;
+    HIP_TRY(env, hipStreamSynchronize((hipStream_t)stream));
+    HIP_TRY(env, hipMemcpy2DAsync(host_dst, (size_t)dst_stride, d.queue + (size_t)slot * d.B * d.instStride, (size_t)d.instStride,
+                                  (size_t)dst_stride, (size_t)d.B, hipMemcpyDeviceToHost, s));
+    HIP_TRY(env, hipStreamSynchronize(s));
     return PCBENV_OK;
 }
 
@@ -391,8 +529,12 @@ extern "C" int pcbenv_step(pcbenv *env, const int32_t *actions_dev, int32_t fmt,
     DEVICE_GUARD(env);
     if (!actions_dev) return fail(env, PCBENV_EINVAL, "null actions");
     if (fmt != PCBENV_ACTION_TUPLE && fmt != PCBENV_ACTION_FLAT) return fail(env, PCBENV_EINVAL, "unknown action format");
+    const int consumes = (env->cfg.flags & PCBENV_FLAG_AUTO_RESET) ? 1 : 0;
+    rc = gen_before_launch(env, consumes, (hipStream_t)stream);
+    if (rc) return rc;
     dispatch_step(env, (int *)actions_dev, fmt, 0, 0, 0, 0, 1, (hipStream_t)stream);
     HIP_TRY(env, hipGetLastError());
+    gen_after_launch(env, consumes, (hipStream_t)stream);
     return PCBENV_OK;
 }
 
@@ -403,8 +545,12 @@ extern "C" int pcbenv_step_sampled(pcbenv *env, int32_t *actions_out_dev, int32_
     DEVICE_GUARD(env);
     if (!actions_out_dev) return fail(env, PCBENV_EINVAL, "null actions");
     if (fmt != PCBENV_ACTION_TUPLE && fmt != PCBENV_ACTION_FLAT) return fail(env, PCBENV_EINVAL, "unknown action format");
+    const int consumes = (env->cfg.flags & PCBENV_FLAG_AUTO_RESET) ? 1 : 0;
+    rc = gen_before_launch(env, consumes, (hipStream_t)stream);
+    if (rc) return rc;
     dispatch_step(env, actions_out_dev, fmt, 1, seed, first_env_index, step_index, 1, (hipStream_t)stream);
     HIP_TRY(env, hipGetLastError());
+    gen_after_launch(env, consumes, (hipStream_t)stream);
     return PCBENV_OK;
 }
 
@@ -438,9 +584,14 @@ extern "C" int pcbenv_get_state(pcbenv *env, void *host_dst, void *stream) {
 }
 extern "C" int pcbenv_set_state(pcbenv *env, const void *host_src, void *stream) {
     if (!env || !host_src) return fail(env, PCBENV_EINVAL, "null argument");
+    if (env->gen_on) return fail(env, PCBENV_ESTATE, "restoring a checkpoint is not supported while the on-device generator runs (its streams are not part of the state)");
     DEVICE_GUARD(env);
     const size_t sb = (size_t)env->dp.stateStride * env->dp.B;
     HIP_TRY(env, hipMemcpyAsync(env->dp.state, host_src, sb, hipMemcpyHostToDevice, (hipStream_t)stream));
+    std::vector<unsigned> cur((size_t)env->dp.B);  // the published copy of the queue cursors follows the restored headers
+    for (int i = 0; i < env->dp.B; i++)
+        cur[(size_t)i] = ((const EnvHdr *)((const unsigned char *)host_src + (size_t)i * env->dp.stateStride))->qcursor;
+    HIP_TRY(env, hipMemcpyAsync(env->dp.cursor_pub, cur.data(), 4 * (size_t)env->dp.B, hipMemcpyHostToDevice, (hipStream_t)stream));
     HIP_TRY(env, hipStreamSynchronize((hipStream_t)stream));
     return PCBENV_OK;
 }
@@ -453,12 +604,20 @@ extern "C" int pcbenv_rollout_sampled(pcbenv *env, int32_t *actions_out_dev, int
     if (!actions_out_dev || num_steps < 0) return fail(env, PCBENV_EINVAL, "bad rollout arguments");
     if (fmt != PCBENV_ACTION_TUPLE && fmt != PCBENV_ACTION_FLAT) return fail(env, PCBENV_EINVAL, "unknown action format");
     if (num_steps == 0) return PCBENV_OK;
+    const bool auto_reset = (env->cfg.flags & PCBENV_FLAG_AUTO_RESET) != 0;
     if (env->cfg.flags & PCBENV_FLAG_INCREMENTAL_OBS) {  // row-incremental tensors: one launch per step, as before
         const size_t per_step = (size_t)env->dp.B * (fmt == PCBENV_ACTION_TUPLE ? 3 : 1);
-        for (int t = 0; t < num_steps; t++)
+        for (int t = 0; t < num_steps; t++) {
+            rc = gen_before_launch(env, auto_reset ? 1 : 0, (hipStream_t)stream);
+            if (rc) return rc;
             dispatch_step(env, actions_out_dev + per_step * (size_t)t, fmt, 1, seed, first_env_index, step_index0 + (uint64_t)t, 1, (hipStream_t)stream);
+            gen_after_launch(env, auto_reset ? 1 : 0, (hipStream_t)stream);
+        }
     } else {
+        rc = gen_before_launch(env, auto_reset ? num_steps : 0, (hipStream_t)stream);  // every step of it may end an episode
+        if (rc) return rc;
         dispatch_step(env, actions_out_dev, fmt, 1, seed, first_env_index, step_index0, num_steps, (hipStream_t)stream);
+        gen_after_launch(env, auto_reset ? num_steps : 0, (hipStream_t)stream);
     }
     HIP_TRY(env, hipGetLastError());
     return PCBENV_OK;

@@ -18,6 +18,7 @@ EXPORTS = ("pcbenv_abi_version", "pcbenv_create", "pcbenv_destroy", "pcbenv_last
            "pcbenv_instance_stride", "pcbenv_max_total_pins", "pcbenv_bind_buffers", "pcbenv_bind_buffers_slots", "pcbenv_select_slot",
            "pcbenv_load_instances", "pcbenv_reset", "pcbenv_step", "pcbenv_sample_actions", "pcbenv_step_sampled", "pcbenv_rollout_sampled",
            "pcbenv_mask_bits", "pcbenv_state_bytes", "pcbenv_get_state", "pcbenv_set_state", "pcbenv_queue_cursors",
+           "pcbenv_instgen_device_enable", "pcbenv_instgen_device_status", "pcbenv_get_instances",
            "pcbenv_instgen_create", "pcbenv_instgen_destroy", "pcbenv_instgen_next", "pcbenv_instgen_next_batch")
 
 
@@ -78,6 +79,9 @@ def load():
     L.pcbenv_instgen_destroy.restype = None
     L.pcbenv_instgen_next.argtypes = [C.c_void_p, C.c_void_p]
     L.pcbenv_instgen_next_batch.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.c_int32]
+    L.pcbenv_instgen_device_enable.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.pcbenv_instgen_device_status.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p]
+    L.pcbenv_get_instances.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     L.pcbenv_rollout_sampled.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]
     L.pcbenv_queue_cursors.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p]
     L.pcbenv_mask_bits.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]

@@ -196,6 +196,31 @@ class BatchedPlacementEnv:
             out.append(packed)
         return out
 
+    def enable_device_instances(self):
+        """Fresh instances at every reset, generated on the device (csrc/pcb_geninst.h): environment i draws stream
+        `env_seed(run_seed, first_env_index + i)`, the same records `generate_instances()` would queue, episode after
+        episode, without the host in the loop.  The library owns the queue from here on."""
+        if self.cfg.kind == KIND_SQUARE:
+            return
+        seeds = np.asarray([env_seed(self.run_seed, self.first_env_index + i) for i in range(self.num_envs)], np.int64)
+        if seeds.min() < 0 or seeds.max() >= 2 ** 32:
+            raise ValueError("stream seeds must fit 32 bits (np.random.seed)")
+        s32 = np.ascontiguousarray(seeds, np.uint32)
+        _lib.check(self._L.pcbenv_instgen_device_enable(self._h, s32.ctypes.data, self._stream()), self._h)
+        self.device_instances = True
+
+    def device_instance_errors(self) -> int:
+        err = C.c_uint32()
+        _lib.check(self._L.pcbenv_instgen_device_status(self._h, C.byref(err), self._stream()), self._h)
+        return int(err.value)
+
+    def queued_instances(self, slot: int) -> np.ndarray:
+        """Packed records of one queue slot, uint8 [B, instance_stride] (synchronises)."""
+        from .instances import instance_stride
+        out = np.zeros((self.num_envs, instance_stride(self.cfg)), np.uint8)
+        _lib.check(self._L.pcbenv_get_instances(self._h, int(slot), out.ctypes.data, self._stream()), self._h)
+        return out
+
     def refill_slot(self, slot: int, native: bool = True):
         """Overwrite one queue slot with every environment's next instance (call when no environment can be
         about to read that slot, e.g. between rollouts; copies are ordered on the current stream)."""

@@ -72,7 +72,7 @@ def test_golden_episodes_on_gpu(name):
 
 
 def _oracle_rollout(cfg, B, episodes, queue_depth=2, p_bad=0.02, incremental=False, auto_reset=False, fused=False,
-                    threads=0, cpu_threads=1, stats=None, max_steps=400, num_slots=1):
+                    threads=0, cpu_threads=1, stats=None, max_steps=400, num_slots=1, device_instances=False):
     """Device-sampled legal actions (plus a few corrupted ones); every observation, reward, done, info of every step
     must equal the CPU oracle's.  Covers reset_done() and the instance queue.  cpu_threads > 1: the oracle steps and
     the whole-batch tensor comparison run under OpenMP (full-size batches).  stats: filled with counts of the
@@ -80,7 +80,14 @@ def _oracle_rollout(cfg, B, episodes, queue_depth=2, p_bad=0.02, incremental=Fal
     from oracle import oracle as orc
     env = BatchedPlacementEnv(cfg, B, queue_depth=queue_depth, run_seed=3, incremental_obs=incremental,
                               auto_reset=auto_reset, threads_per_env=threads, num_slots=num_slots)
-    packed = env.generate_instances(verify=4) if cfg.kind != KIND_SQUARE else None
+    if device_instances:  # fresh instances from the on-device generator; the oracle takes the host generator's records
+        from pcbenv.instances import NativeInstanceStreams
+        env.enable_device_instances()
+        host = NativeInstanceStreams(cfg, [env_seed(3, i) for i in range(B)])
+        fresh = [host.next_packed() for _ in range(max_steps + 2)]  # an environment resets at most once per step
+        packed = None
+    else:
+        packed = env.generate_instances(verify=4) if cfg.kind != KIND_SQUARE else None
     ob = orc.OracleBatch(cfg, B)
     cursor = np.zeros(B, np.int64)
 
@@ -88,6 +95,11 @@ def _oracle_rollout(cfg, B, episodes, queue_depth=2, p_bad=0.02, incremental=Fal
         if cfg.kind == KIND_SQUARE:
             for i in np.flatnonzero(mask):
                 ob.env(i).reset()
+            return
+        if device_instances:
+            rec = np.stack([fresh[min(cursor[i], len(fresh) - 1)][i] for i in range(B)])
+            ob.reset_packed(rec, mask.astype(np.uint8), cpu_threads)
+            cursor[mask.astype(bool)] += 1
             return
         rec = np.where((cursor % queue_depth == 0)[:, None], packed[0], packed[1 % queue_depth]) if queue_depth <= 2 else \
             np.stack([packed[cursor[i] % queue_depth][i] for i in range(B)])
@@ -145,6 +157,8 @@ def _oracle_rollout(cfg, B, episodes, queue_depth=2, p_bad=0.02, incremental=Fal
             oracle_reset(d)
         steps += B
         t += 1
+    if device_instances:
+        assert env.device_instance_errors() == 0 and int(cursor.max()) < len(fresh)
     env.close()
     if stats is not None:
         stats["env_steps"] = steps
@@ -498,6 +512,62 @@ def test_persistent_rollout_fills_the_trajectory(name, B, T, S):
         for k in traj:
             assert ob.first_mismatch(k, traj[k][s_], 8) < 0, (t, k)
     env.close(); single.close()
+
+
+GEN_CASES = {
+    "c2": lambda: named_config("c2"), "c3": lambda: named_config("c3"), "c4": lambda: named_config("c4"),
+    "c5": lambda: named_config("c5"),
+    # min < max everywhere: truncated multinomial (step 7), clamped component counts, net / pin clipping
+    "small_spatial": lambda: EnvConfig.spatial(10, 10, 3, 4, 2, 4, 2, 4, 6, 1, 2, 4, 5, 2, "centroid", 2, 0.5),
+    "small_pin": lambda: EnvConfig.pin(10, 10, 3, 4, 2, 4, 2, 4, 6, 1, 2, 4, 5, 2, "centroid", 2, 0.5),
+    "mid_spatial": lambda: EnvConfig.spatial(12, 12, 5, 5, 2, 5, 2, 5, 8, 6, 3, 5, 7, 2, "centroid", 2, 0.25),
+    "rect_6x6": lambda: EnvConfig.rect(6, 6, 2, 4, 2, 4, 4, 2),
+}
+
+
+@pytest.mark.parametrize("name,B", [("c2", 2048), ("c3", 4096), ("c4", 1024), ("c5", 512), ("small_spatial", 4096),
+                                    ("small_pin", 4096), ("mid_spatial", 2048), ("rect_6x6", 1024)])
+def test_device_instance_generator_equals_the_host_streams(name, B):
+    """k_gen_fill against csrc/instance_gen.cpp (itself pinned to the reference's generate_instances by
+    test_instance_gen_native.py and the golden tables): the whole queue after enabling, and -- after rollouts that
+    consume and refill it several times over -- every record an environment is about to take."""
+    from pcbenv.instances import NativeInstanceStreams
+    cfg = GEN_CASES[name]()
+    Q = 8
+    env = BatchedPlacementEnv(cfg, B, queue_depth=Q, run_seed=7, auto_reset=True)
+    env.enable_device_instances()
+    host = NativeInstanceStreams(cfg, [env_seed(7, i) for i in range(B)])
+    K = 80
+    recs = [host.next_packed() for _ in range(K)]
+    for s_ in range(Q):
+        got = env.queued_instances(s_)
+        bad = np.flatnonzero((got != recs[s_]).any(axis=1))
+        assert len(bad) == 0, (name, s_, bad[:5])
+    env.reset()
+    for t in range(60):
+        env.rollout_step(t)
+    assert env.device_instance_errors() == 0
+    sd = env.state_dict()["state"].reshape(B, -1)
+    cursor = sd[:, 12:16].copy().view(np.uint32)[:, 0].astype(np.int64)   # EnvHdr::qcursor
+    assert cursor.min() >= 2 and cursor.max() < K - Q, (cursor.min(), cursor.max())
+    slots = [env.queued_instances(s_) for s_ in range(Q)]
+    for i in range(0, B, 3):  # device_instance_errors() brought the queue up to date: records cursor .. cursor + Q - 1
+        for ahead in range(Q):
+            r = int(cursor[i]) + ahead
+            assert np.array_equal(slots[r % Q][i], recs[r][i]), (name, i, r)
+    env.close()
+
+
+@pytest.mark.parametrize("name,B,mode", [("c3", 256, "fused"), ("c4", 128, "fused"), ("c2", 256, "explicit"), ("small_spatial", 256, "fused"),
+                                         ("small_pin", 256, "explicit"), ("mid_spatial", 128, "fused")])
+def test_fresh_instances_every_reset_vs_oracle(name, B, mode):
+    """The reference's reset() semantics at full speed: every episode of every environment on a NEW instance from its
+    stream (on-device generator, queue refilled on the side stream while the steps run); every tensor, reward, done
+    and info against the oracle resetting from the host generator's records."""
+    cfg = GEN_CASES[name]()
+    fused = mode == "fused"
+    _oracle_rollout(cfg, B, episodes=7, queue_depth=4, p_bad=0.0 if fused else 0.02, auto_reset=fused, fused=fused,
+                    device_instances=True, max_steps=150)
 
 
 def test_flat_actions_equal_tuple_actions():

@@ -57,9 +57,12 @@ def rollout_leg(cfg, args, B, dev_index, rank, T):
     in their own slot of [T + 1, B, ...] buffers -- the on-device counterpart of the reference's simulate() loop."""
     from pcbenv.batched_env import BatchedPlacementEnv
     S = T + 1
-    env = BatchedPlacementEnv(cfg, B, device=f"cuda:{dev_index}", queue_depth=max(args.queue_depth, 4), run_seed=args.run_seed,
-                              first_env_index=rank * B, auto_reset=True, threads_per_env=args.threads_per_env, num_slots=S)
-    env.generate_instances()
+    env = BatchedPlacementEnv(cfg, B, device=f"cuda:{dev_index}", queue_depth=4 * T if args.instances == "device" else max(args.queue_depth, 4),
+                              run_seed=args.run_seed, first_env_index=rank * B, auto_reset=True, threads_per_env=args.threads_per_env, num_slots=S)
+    if args.instances == "device":
+        env.enable_device_instances()
+    else:
+        env.generate_instances()
     env.reset()
     acts = torch.empty((T, B, 3), dtype=torch.int32, device=env.device)
     launches = max(1, args.steps // T)
@@ -77,12 +80,14 @@ def rollout_leg(cfg, args, B, dev_index, rank, T):
     dt = time.perf_counter() - t0
     kernel_ms = ev[0].elapsed_time(ev[1]) / launches
     nbytes = trajectory_bytes_per_env_step(cfg)
+    gen_errors = env.device_instance_errors() if args.instances == "device" else None
     env.close()
     gbps = nbytes * B * T / (kernel_ms * 1e-3) / 1e9
     return {"value": round(B * T * launches / dt, 1), "unit": "env-steps/s", "steps_per_launch": T, "num_slots": S,
             "launches": launches, "ms_per_step": round(dt / (launches * T) * 1e3, 5), "kernel_ms_per_launch": round(kernel_ms, 4),
             "bytes_written_per_env_step": nbytes, "achieved_GBps": round(gbps, 1), "frac_of_8TBps": round(gbps / 8000.0, 4),
             "algorithmic_GBps": round(algorithmic_bytes_per_env_step(cfg) * B * T / (kernel_ms * 1e-3) / 1e9, 1),
+            "instances": args.instances, "generator_errors": gen_errors,
             "note": "every tensor of every step kept (trajectory layout), float64 feature tensors included; this rank only"}
 
 
@@ -184,7 +189,11 @@ def main():
     ap.add_argument("--config", default="c3", help="c2 | c3 | c4 | c5 (SURVEY.md §8)")
     ap.add_argument("--reward", default="centroid", choices=["centroid", "beam", "both"])
     ap.add_argument("--envs", type=int, default=0, help="environments per GPU (default: the config's batch)")
-    ap.add_argument("--queue-depth", type=int, default=2)
+    ap.add_argument("--queue-depth", type=int, default=0, help="instances queued per environment (default: 2 for replay, 32 for device)")
+    ap.add_argument("--instances", default="device", choices=["device", "replay"],
+                    help="device: every reset takes a FRESH instance of the environment's reference-exact stream, generated on "
+                         "the GPU while the steps run (the reference's reset() semantics); replay: the queue is filled once by "
+                         "the host generator before the timed region and replayed round robin (round-1 behaviour)")
     ap.add_argument("--run-seed", type=int, default=0)
     ap.add_argument("--incremental", action="store_true", help="PCBENV_FLAG_INCREMENTAL_OBS")
     ap.add_argument("--chunk", type=int, default=1,
@@ -247,13 +256,19 @@ def main():
     from pcbenv import named_config
     from pcbenv.batched_env import BatchedPlacementEnv
     cfg = named_config(args.config, args.reward)
+    if args.queue_depth <= 0:
+        args.queue_depth = 32 if args.instances == "device" else 2
     default_B = {"c1": 1, "c2": 1024, "c3": 4096, "c4": 4096, "c5": 8192}[args.config]
     B = args.envs or default_B
     env = BatchedPlacementEnv(cfg, B, device=f"cuda:{dev_index}", queue_depth=args.queue_depth,
                               run_seed=args.run_seed, first_env_index=rank * B, incremental_obs=args.incremental,
                               auto_reset=(args.loop == "fused"), threads_per_env=args.threads_per_env)
     t_gen = time.perf_counter()
-    env.generate_instances()
+    if args.instances == "device":
+        env.enable_device_instances()
+    else:
+        env.generate_instances()
+    torch.cuda.synchronize()
     t_gen = time.perf_counter() - t_gen
     env.reset()
     actions = torch.empty((B, 3), dtype=torch.int32, device=env.device)
@@ -336,6 +351,7 @@ def main():
             torch.cuda.synchronize()
             step_kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
 
+    gen_errors_main = env.device_instance_errors() if args.instances == "device" and cfg.kind != 0 else None
     env.close()
     rollout = None
     if args.rollout_steps > 0 and not args.incremental and args.config != "c1":
@@ -393,10 +409,11 @@ def main():
                 "backend": (("rccl" if args.backend == "nccl" else args.backend) if dist else None),
                 "adv_allgather_bytes_per_rank": (16 * B * 4 if adv is not None else 0),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
-                "data": "synthetic (reference-exact instance generator, seeds 1000003*run_seed+env; uniform legal actions drawn on device)",
+                "data": "synthetic (reference-exact instance streams, seeds 1000003*run_seed+env" + (", generated on the GPU, a new instance at every reset" if args.instances == "device" else ", queued once and replayed") + "; uniform legal actions drawn on device)",
                 "config": {"workload": f"{args.config}: {cfg.height}x{cfg.width} grid, {cfg.max_num_components} components, "
                                        f"{cfg.max_total_pins} pins, reward={args.reward}", "envs_per_gpu": B,
-                           "queue_depth": args.queue_depth, "incremental_obs": bool(args.incremental), "loop": args.loop, "steps_per_host_call": chunk,
+                           "queue_depth": args.queue_depth, "instances": args.instances,
+                           "fresh_instance_every_reset": args.instances == "device", "generator_errors": gen_errors_main, "incremental_obs": bool(args.incremental), "loop": args.loop, "steps_per_host_call": chunk,
                            "instance_generation_s": round(t_gen, 2),
                            "store_policy": "sc1 nt (streaming)" if cfg.cell_tensor_bytes_per_step(args.incremental) * B
                            > int(os.environ.get("PCBENV_STREAM_THRESHOLD_MB", "256")) * (1 << 20) else "sc1 (write-through)"},

@@ -423,7 +423,7 @@ static int check_queue(pcbenv *env) {
 static void gen_start_fill(pcbenv *env, hipStream_t main) {
     hipEventRecord(env->ev_snap, main);
     hipStreamWaitEvent(env->gen_stream, env->ev_snap, 0);
-    hipLaunchKernelGGL(k_gen_fill, dim3((env->dp.B + WAVE - 1) / WAVE), dim3(WAVE), 0, env->gen_stream, env->gp);
+    hipLaunchKernelGGL(k_gen_fill, dim3(env->dp.B), dim3(WAVE), 0, env->gen_stream, env->gp);
     hipEventRecord(env->ev_fill, env->gen_stream);
     env->gen_outstanding = true;
     env->since_outstanding = 0;
@@ -478,7 +478,7 @@ extern "C" int pcbenv_instgen_device_enable(pcbenv *env, const uint32_t *seeds_h
     HIP_TRY(env, hipEventCreateWithFlags(&env->ev_fill, hipEventDisableTiming));
     const dim3 grid((d.B + WAVE - 1) / WAVE);
     hipLaunchKernelGGL(k_gen_seed, grid, dim3(WAVE), 0, s, g, seeds_dev);
-    hipLaunchKernelGGL(k_gen_fill, grid, dim3(WAVE), 0, s, g);  // the whole queue, before anything can consume it
+    hipLaunchKernelGGL(k_gen_fill, dim3(d.B), dim3(WAVE), 0, s, g);  // the whole queue, before anything can consume it
     HIP_TRY(env, hipGetLastError());
     HIP_TRY(env, hipStreamSynchronize(s));
     hipFree(seeds_dev);

@@ -1,0 +1,56 @@
+// Stand-alone check of the on-device instance generator against the host twin (diagnostic tool, not shipped):
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 -Iinclude -Irl-environment-for-component-placement_amd/csrc \
+//         tools/gen_harness.hip rl-environment-for-component-placement_amd/csrc/instance_gen.cpp -o ab/gen_harness && ab/gen_harness
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+#include "pcbenv.h"
+#include "pcb_geninst.h"
+extern "C" int32_t pcbenv_max_total_pins(const pcbenv_config *c) {
+    long long a = (long long)c->max_num_pins_per_net * c->max_num_nets, b = (long long)c->max_num_components * c->max_component_h * c->max_component_w;
+    return c->kind >= 2 ? (int32_t)(a < b ? a : b) : 0;
+}
+extern "C" int64_t pcbenv_instance_stride(const pcbenv_config *c) { return 16 + 8ll * (c->max_num_components + pcbenv_max_total_pins(c)); }
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+int main(int argc, char **argv) {
+    pcbenv_config c; memset(&c, 0, sizeof(c));
+    const int which = argc > 1 ? atoi(argv[1]) : 1;
+    c.kind = which; c.height = c.width = which == 1 ? 32 : 64;
+    c.min_component_w = c.min_component_h = 2; c.max_component_w = c.max_component_h = 6;
+    c.max_num_components = c.min_num_components = which == 1 ? 8 : 16;
+    c.net_distribution = 9; c.pin_spread = 9; c.min_num_nets = c.max_num_nets = 8; c.max_num_pins_per_net = c.min_num_pins_per_net = 6;
+    c.reward_type = 1; c.reward_beam_width = 2; c.weight_wirelength = 0.5; c.weight_num_intersections = 0.5;
+    const int B = 256, Q = 4;
+    c.num_envs = B; c.queue_depth = Q;
+    const long long stride = pcbenv_instance_stride(&c), istride = (stride + 15) & ~15ll;
+    GenParams g; memset(&g, 0, sizeof(g));
+    g.kind = c.kind; g.C = c.max_num_components; g.P = pcbenv_max_total_pins(&c); g.Q = Q; g.B = B;
+    g.min_comp = c.min_num_components; g.max_comp = c.max_num_components; g.min_h = g.min_w = 2; g.max_h = g.max_w = 6;
+    g.min_nets = g.max_nets = 8; g.min_ppn = g.max_ppn = 6; g.net_distribution = 9; g.pin_spread = 9; g.instStride = istride;
+    unsigned *cursor, *seeds; unsigned char *queue;
+    CK(hipMalloc((void **)&g.gen, sizeof(GenState) * B)); CK(hipMalloc((void **)&g.produced, 4 * B));
+    CK(hipMalloc((void **)&cursor, 4 * B)); CK(hipMalloc((void **)&seeds, 4 * B)); CK(hipMalloc((void **)&queue, (size_t)istride * B * Q));
+    CK(hipMemset(cursor, 0, 4 * B)); CK(hipMemset(queue, 0xEE, (size_t)istride * B * Q));
+    std::vector<unsigned> hs(B); for (int i = 0; i < B; i++) hs[i] = 7000021u + i;
+    CK(hipMemcpy(seeds, hs.data(), 4 * B, hipMemcpyHostToDevice));
+    g.queue = queue; g.cursor_pub = cursor;
+    printf("stride %lld istride %lld P %d sizeof(GenState) %zu sizeof(GenLds) %zu\n", stride, istride, g.P, sizeof(GenState), sizeof(GenLds)); fflush(stdout);
+    hipLaunchKernelGGL(k_gen_seed, dim3((B + 63) / 64), dim3(64), 0, 0, g, seeds);
+    CK(hipDeviceSynchronize()); printf("seed ok\n"); fflush(stdout);
+    hipLaunchKernelGGL(k_gen_fill, dim3(B), dim3(64), 0, 0, g);
+    CK(hipGetLastError()); CK(hipDeviceSynchronize()); printf("fill ok\n"); fflush(stdout);
+    std::vector<unsigned char> dev((size_t)istride * B * Q), host((size_t)stride);
+    CK(hipMemcpy(dev.data(), queue, dev.size(), hipMemcpyDeviceToHost));
+    int bad = 0;
+    for (int i = 0; i < B; i++) {
+        pcbenv_instgen *s; if (pcbenv_instgen_create(&c, hs[i], &s)) { printf("create failed\n"); return 1; }
+        for (int r = 0; r < Q; r++) {
+            pcbenv_instgen_next(s, host.data());
+            if (memcmp(host.data(), dev.data() + ((size_t)r * B + i) * istride, (size_t)stride)) { if (bad < 5) printf("mismatch env %d record %d\n", i, r); bad++; }
+        }
+        pcbenv_instgen_destroy(s);
+    }
+    printf("%d of %d records differ\n", bad, B * Q);
+    return bad != 0;
+}

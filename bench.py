@@ -189,7 +189,7 @@ def main():
     ap.add_argument("--config", default="c3", help="c2 | c3 | c4 | c5 (SURVEY.md §8)")
     ap.add_argument("--reward", default="centroid", choices=["centroid", "beam", "both"])
     ap.add_argument("--envs", type=int, default=0, help="environments per GPU (default: the config's batch)")
-    ap.add_argument("--queue-depth", type=int, default=0, help="instances queued per environment (default: 2 for replay, 32 for device)")
+    ap.add_argument("--queue-depth", type=int, default=0, help="instances queued per environment (default: 2 for replay, 64 for device)")
     ap.add_argument("--instances", default="device", choices=["device", "replay"],
                     help="device: every reset takes a FRESH instance of the environment's reference-exact stream, generated on "
                          "the GPU while the steps run (the reference's reset() semantics); replay: the queue is filled once by "
@@ -257,7 +257,7 @@ def main():
     from pcbenv.batched_env import BatchedPlacementEnv
     cfg = named_config(args.config, args.reward)
     if args.queue_depth <= 0:
-        args.queue_depth = 32 if args.instances == "device" else 2
+        args.queue_depth = 64 if args.instances == "device" else 2
     default_B = {"c1": 1, "c2": 1024, "c3": 4096, "c4": 4096, "c5": 8192}[args.config]
     B = args.envs or default_B
     env = BatchedPlacementEnv(cfg, B, device=f"cuda:{dev_index}", queue_depth=args.queue_depth,

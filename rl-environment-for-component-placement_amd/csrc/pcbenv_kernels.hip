@@ -42,6 +42,7 @@ struct pcbenv {
     // on-device instance generator (pcbenv_instgen_device_enable): side stream + the bookkeeping that guarantees a
     // record is complete before any launch can consume it (see gen_before_launch)
     bool gen_on, gen_outstanding;
+    int gen_grid;  // workgroups of a refill launch (GEN_MAX_GRID; PCBENV_GEN_GRID overrides, for experiments)
     GenParams gp;
     hipStream_t gen_stream;
     hipEvent_t ev_snap, ev_fill;
@@ -418,12 +419,12 @@ static int check_queue(pcbenv *env) {
 // snapshot.  A launch may consume at most n records per environment (one per reset, one per step with
 // PCBENV_FLAG_AUTO_RESET, num_steps per rollout), so a launch is safe as long as the launches since the snapshot of
 // the last fill the caller's stream has waited for add up to at most queue_depth; `since_waited` keeps that sum.
-// Fills are started early (a quarter of the queue consumed at worst) and waited for late, so they overlap the step
+// Fills are started early (half of the queue consumed at worst) and waited for late, so they overlap the step
 // kernels; the wait is a stream-side event wait, never a host synchronisation.
 static void gen_start_fill(pcbenv *env, hipStream_t main) {
     hipEventRecord(env->ev_snap, main);
     hipStreamWaitEvent(env->gen_stream, env->ev_snap, 0);
-    hipLaunchKernelGGL(k_gen_fill, dim3(env->dp.B), dim3(WAVE), 0, env->gen_stream, env->gp);
+    hipLaunchKernelGGL(k_gen_fill, dim3(env->dp.B < env->gen_grid ? env->dp.B : env->gen_grid), dim3(WAVE), GEN_LDS_BYTES(env->gp.instStride), env->gen_stream, env->gp);
     hipEventRecord(env->ev_fill, env->gen_stream);
     env->gen_outstanding = true;
     env->since_outstanding = 0;
@@ -450,7 +451,7 @@ static void gen_after_launch(pcbenv *env, int n, hipStream_t main) {
     if (!env->gen_on) return;
     env->since_waited += n;
     if (env->gen_outstanding) env->since_outstanding += n;
-    else if (env->since_waited * 4 >= env->dp.Q) gen_start_fill(env, main);
+    else if (env->since_waited * 2 >= env->dp.Q) gen_start_fill(env, main);
 }
 
 extern "C" int pcbenv_instgen_device_enable(pcbenv *env, const uint32_t *seeds_host, void *stream) {
@@ -473,18 +474,24 @@ extern "C" int pcbenv_instgen_device_enable(pcbenv *env, const uint32_t *seeds_h
     HIP_TRY(env, hipMalloc((void **)&g.produced, 4 * (size_t)d.B + 4));
     HIP_TRY(env, hipMalloc((void **)&seeds_dev, 4 * (size_t)d.B));
     HIP_TRY(env, hipMemcpyAsync(seeds_dev, seeds_host, 4 * (size_t)d.B, hipMemcpyHostToDevice, s));
-    HIP_TRY(env, hipStreamCreateWithFlags(&env->gen_stream, hipStreamNonBlocking));
+    {   // lowest priority: when both queues have workgroups to place, the step kernel's go first
+        int lo_prio = 0, hi_prio = 0;
+        HIP_TRY(env, hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio));
+        HIP_TRY(env, hipStreamCreateWithPriority(&env->gen_stream, hipStreamNonBlocking, lo_prio));
+    }
     HIP_TRY(env, hipEventCreateWithFlags(&env->ev_snap, hipEventDisableTiming));
     HIP_TRY(env, hipEventCreateWithFlags(&env->ev_fill, hipEventDisableTiming));
     const dim3 grid((d.B + WAVE - 1) / WAVE);
     hipLaunchKernelGGL(k_gen_seed, grid, dim3(WAVE), 0, s, g, seeds_dev);
-    hipLaunchKernelGGL(k_gen_fill, dim3(d.B), dim3(WAVE), 0, s, g);  // the whole queue, before anything can consume it
+    hipLaunchKernelGGL(k_gen_fill, dim3(d.B), dim3(WAVE), GEN_LDS_BYTES(g.instStride), s, g);  // the whole queue, before anything can consume it
     HIP_TRY(env, hipGetLastError());
     HIP_TRY(env, hipStreamSynchronize(s));
     hipFree(seeds_dev);
     env->dp.gen_produced = g.produced;
     env->dp.gen_errors = g.produced + d.B;  // one word behind the counters
     HIP_TRY(env, hipMemsetAsync(env->dp.gen_errors, 0, 4, s));
+    env->gen_grid = GEN_MAX_GRID;
+    if (const char *ev = getenv("PCBENV_GEN_GRID")) { const int v = atoi(ev); if (v >= 1) env->gen_grid = v; }
     env->gen_on = true; env->gen_outstanding = false;
     env->since_waited = 0; env->since_outstanding = 0;
     return PCBENV_OK;

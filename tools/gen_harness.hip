@@ -1,10 +1,11 @@
 // Stand-alone check of the on-device instance generator against the host twin (diagnostic tool, not shipped):
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 -Iinclude -Irl-environment-for-component-placement_amd/csrc \
-//         tools/gen_harness.hip rl-environment-for-component-placement_amd/csrc/instance_gen.cpp -o ab/gen_harness && ab/gen_harness
+//         [-DGEN_STAMPS] tools/gen_harness.hip rl-environment-for-component-placement_amd/csrc/instance_gen.cpp -o ab/gen_harness && ab/gen_harness
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string.h>
 #include <vector>
+#include <algorithm>
 #include "pcbenv.h"
 #include "pcb_geninst.h"
 extern "C" int32_t pcbenv_max_total_pins(const pcbenv_config *c) {
@@ -38,8 +39,25 @@ int main(int argc, char **argv) {
     printf("stride %lld istride %lld P %d sizeof(GenState) %zu sizeof(GenLds) %zu\n", stride, istride, g.P, sizeof(GenState), sizeof(GenLds)); fflush(stdout);
     hipLaunchKernelGGL(k_gen_seed, dim3((B + 63) / 64), dim3(64), 0, 0, g, seeds);
     CK(hipDeviceSynchronize()); printf("seed ok\n"); fflush(stdout);
-    hipLaunchKernelGGL(k_gen_fill, dim3(B), dim3(64), 0, 0, g);
-    CK(hipGetLastError()); CK(hipDeviceSynchronize()); printf("fill ok\n"); fflush(stdout);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(k_gen_fill, dim3(B), dim3(64), GEN_LDS_BYTES(g.instStride), 0, g);
+    hipEventRecord(e1, 0);
+    CK(hipGetLastError()); CK(hipDeviceSynchronize());
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    printf("fill ok: %d wavefronts x %d records in %.1f us on an idle GPU = %.1f us per record per wavefront\n", B, Q, ms * 1e3, ms * 1e3 / Q); fflush(stdout);
+#ifdef GEN_STAMPS
+    {
+        std::vector<GenState> st(B);
+        CK(hipMemcpy(st.data(), g.gen, sizeof(GenState) * B, hipMemcpyDeviceToHost));
+        const char *names[] = {"zero rec + steps 1-2 (sizes)", "steps 3-5 (nets, pins, softmax)", "steps 6-7 (truncated multinomial)", "steps 8-9 (pins -> components)", "swap NumPy out / CPython in", "step 10 (cells)", "write pins + swap CPython out", ""};
+        for (int k = 0; k < 8; k++) {
+            std::vector<long long> d(B); for (int i = 0; i < B; i++) d[i] = (long long)(st[i].stamps[k + 1 > 7 ? 7 : k + 1] - st[i].stamps[k]);
+            std::sort(d.begin(), d.end());
+            if (k < 7) printf("  %-36s median %8lld cycles\n", names[k], d[B / 2]);
+        }
+    }
+#endif
     std::vector<unsigned char> dev((size_t)istride * B * Q), host((size_t)stride);
     CK(hipMemcpy(dev.data(), queue, dev.size(), hipMemcpyDeviceToHost));
     int bad = 0;

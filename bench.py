@@ -3,18 +3,21 @@
 
     python bench.py --gpus N --steps K --warmup W [--config c3] [--reward centroid] [--envs 4096]
 
-A "step" is one batched transition of all environments on a GPU: on-device uniform
-sampling of a legal action, `pcbenv_step` (place + legal mask + observations + the
-terminal routing reward), and the explicit `reset_done()` that follows every
-terminal transition (instances come from the per-environment queue in HBM, filled
-before the timed region from reference-exact RNG streams).  Environments shard by
-global index over ranks with no data-path collective (weak scaling).
+A "step" is one batched transition of all environments on a GPU, one kernel launch: on-device uniform
+sampling of a legal action, the transition (place + legal mask + observations + the terminal routing
+reward) and, after a terminal transition, the reset inside the same launch.  The headline replays a
+queue of instances filled before the timed region from reference-exact RNG streams (as in round 1);
+`fresh_instances` in the line is the same loop where every reset takes a NEW instance of the
+environment's stream, generated on the GPU while the steps run (the reference's reset() semantics,
+`--instances device`), `rollout` the persistent kernel that runs 16 steps per launch and keeps every
+step's tensors (trajectory layout).  Environments shard
+by global index over ranks with no data-path collective (weak scaling); `python bench.py --gpus N`
+starts the N ranks itself.
 
-One JSON line on rank 0: metric/value (whole-job env-steps/s), `roofline` for the
-dominant kernel (k_step: algorithmic bytes per launch / mean launch duration from
-HIP events on the launch stream), and `cpu_baseline` (the oracle restatement of the
-reference, timed on this box's host cores over a bounded sample of the same
-instances and the same action stream, with a parity check of rewards/dones).
+One JSON line on rank 0: metric/value (whole-job env-steps/s), `roofline` for the dominant kernel
+(k_step: algorithmic bytes per launch / mean launch duration from HIP events on the launch stream), and
+`cpu_baseline` (the oracle restatement of the reference, timed on this box's host cores over a bounded
+sample of the same instances and the same action stream, with a parity check of rewards/dones).
 """
 import argparse
 import json
@@ -89,6 +92,32 @@ def rollout_leg(cfg, args, B, dev_index, rank, T):
             "algorithmic_GBps": round(algorithmic_bytes_per_env_step(cfg) * B * T / (kernel_ms * 1e-3) / 1e9, 1),
             "instances": args.instances, "generator_errors": gen_errors,
             "note": "every tensor of every step kept (trajectory layout), float64 feature tensors included; this rank only"}
+
+
+def fresh_instances_leg(cfg, args, B, dev_index, rank):
+    """The same fused loop with the reference's reset() semantics: every reset takes a FRESH instance of the
+    environment's stream, generated on the GPU (k_gen_fill on a side stream) while the steps run.  Timed over at
+    least 256 steps so that the region holds several refills whatever --steps is."""
+    from pcbenv.batched_env import BatchedPlacementEnv
+    steps = max(args.steps, 256)
+    env = BatchedPlacementEnv(cfg, B, device=f"cuda:{dev_index}", queue_depth=64, run_seed=args.run_seed, first_env_index=rank * B,
+                              auto_reset=True, threads_per_env=args.threads_per_env)
+    env.enable_device_instances()
+    env.reset()
+    actions = torch.empty((B, 3), dtype=torch.int32, device=env.device)
+    for t in range(max(args.warmup, 64)):
+        env.rollout_step(t, out=actions)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        env.rollout_step(64 + k, out=actions)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    errors = env.device_instance_errors()
+    env.close()
+    return {"value": round(B * steps / dt, 1), "unit": "env-steps/s", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 5),
+            "queue_depth": 64, "generator_errors": errors,
+            "note": "same loop and kernel; a new instance at every reset, generated on the GPU inside the timed region; this rank only"}
 
 
 def host_cpu_model():
@@ -190,10 +219,12 @@ def main():
     ap.add_argument("--reward", default="centroid", choices=["centroid", "beam", "both"])
     ap.add_argument("--envs", type=int, default=0, help="environments per GPU (default: the config's batch)")
     ap.add_argument("--queue-depth", type=int, default=0, help="instances queued per environment (default: 2 for replay, 64 for device)")
-    ap.add_argument("--instances", default="device", choices=["device", "replay"],
-                    help="device: every reset takes a FRESH instance of the environment's reference-exact stream, generated on "
-                         "the GPU while the steps run (the reference's reset() semantics); replay: the queue is filled once by "
-                         "the host generator before the timed region and replayed round robin (round-1 behaviour)")
+    ap.add_argument("--instances", default="replay", choices=["device", "replay"],
+                    help="replay (the headline, comparable with round 1): the queue is filled once by the host generator before "
+                         "the timed region and replayed round robin; device: every reset takes a FRESH instance of the "
+                         "environment's reference-exact stream, generated on the GPU while the steps run (the reference's "
+                         "reset() semantics) -- with the default `replay` that variant is timed as well and reported as "
+                         "`fresh_instances`")
     ap.add_argument("--run-seed", type=int, default=0)
     ap.add_argument("--incremental", action="store_true", help="PCBENV_FLAG_INCREMENTAL_OBS")
     ap.add_argument("--chunk", type=int, default=1,
@@ -213,6 +244,7 @@ def main():
     ap.add_argument("--rollout-steps", type=int, default=16,
                     help="also time the persistent rollout kernel with this many steps per launch in the trajectory layout "
                          "(reported as `rollout`; 0 = skip)")
+    ap.add_argument("--no-fresh-leg", action="store_true", help="skip the extra leg with a fresh on-device instance at every reset")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     args = ap.parse_args()
@@ -353,6 +385,9 @@ def main():
 
     gen_errors_main = env.device_instance_errors() if args.instances == "device" and cfg.kind != 0 else None
     env.close()
+    fresh = None
+    if args.instances == "replay" and args.loop == "fused" and not args.incremental and cfg.kind != 0 and not args.no_fresh_leg:
+        fresh = fresh_instances_leg(cfg, args, B, dev_index, rank)
     rollout = None
     if args.rollout_steps > 0 and not args.incremental and args.config != "c1":
         if dist:
@@ -417,7 +452,7 @@ def main():
                            "instance_generation_s": round(t_gen, 2),
                            "store_policy": "sc1 nt (streaming)" if cfg.cell_tensor_bytes_per_step(args.incremental) * B
                            > int(os.environ.get("PCBENV_STREAM_THRESHOLD_MB", "256")) * (1 << 20) else "sc1 (write-through)"},
-                "roofline": roof, "cpu_baseline": cpu, "rollout": rollout}
+                "roofline": roof, "cpu_baseline": cpu, "fresh_instances": fresh, "rollout": rollout}
         print(json.dumps(line), flush=True)
     if dist:
         dist.destroy_process_group()

@@ -419,7 +419,8 @@ static int check_queue(pcbenv *env) {
 // snapshot.  A launch may consume at most n records per environment (one per reset, one per step with
 // PCBENV_FLAG_AUTO_RESET, num_steps per rollout), so a launch is safe as long as the launches since the snapshot of
 // the last fill the caller's stream has waited for add up to at most queue_depth; `since_waited` keeps that sum.
-// Fills are started early (half of the queue consumed at worst) and waited for late, so they overlap the step
+// Fills are started early (half of the queue consumed at worst; fewer, larger refills cost the step kernels less than
+// many small ones) and waited for late, so they overlap the step
 // kernels; the wait is a stream-side event wait, never a host synchronisation.
 static void gen_start_fill(pcbenv *env, hipStream_t main) {
     hipEventRecord(env->ev_snap, main);

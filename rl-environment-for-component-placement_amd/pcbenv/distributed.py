@@ -56,3 +56,30 @@ def normalize_advantages(adv: torch.Tensor, mode: str = "all_gather", eps: float
     concatenation of all shards."""
     mean, std = global_mean_std(adv, mode, eps)
     return (adv - mean) / torch.clamp(std, min=eps)
+
+
+def broadcast_module(module: torch.nn.Module, src: int = 0) -> None:
+    """Every rank starts from rank `src`'s parameters AND buffers (BatchNorm running statistics): averaged gradients
+    are only meaningful when they are applied to identical weights."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t.data, src)
+
+
+def allreduce_mean_(tensors) -> None:
+    """In-place mean over ranks of a list of tensors as ONE flat collective (gradient buckets, BatchNorm statistics)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    tensors = [t for t in tensors if t is not None and t.is_floating_point()]
+    if not tensors:
+        return
+    flat = torch.cat([t.reshape(-1) for t in tensors])
+    dist.all_reduce(flat)
+    flat /= dist.get_world_size()
+    off = 0
+    for t in tensors:
+        n = t.numel()
+        t.copy_(flat[off:off + n].view_as(t))
+        off += n

@@ -15,7 +15,7 @@ from typing import Dict, List
 import torch
 import torch.distributed as dist
 
-from .distributed import normalize_advantages
+from .distributed import allreduce_mean_, broadcast_module, normalize_advantages
 
 
 @dataclass
@@ -33,31 +33,34 @@ class PPOConfig:
 
 
 def _allreduce_grads(model):
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return
-    flat = torch.cat([p.grad.reshape(-1) for p in model.parameters() if p.grad is not None])
-    dist.all_reduce(flat)
-    flat /= dist.get_world_size()
-    off = 0
-    for p in model.parameters():
-        if p.grad is not None:
-            n = p.grad.numel()
-            p.grad.copy_(flat[off:off + n].view_as(p.grad))
-            off += n
+    allreduce_mean_([p.grad for p in model.parameters() if p.grad is not None])
 
 
 class PPOTrainer:
     def __init__(self, env, policy, cfg: PPOConfig = PPOConfig(), obs_keys=("grid", "pin_grid", "component_grid", "placement_mask", "action_mask")):
         assert env.auto_reset, "create the environment with auto_reset=True"
         self.env, self.policy, self.cfg, self.obs_keys = env, policy, cfg, obs_keys
+        broadcast_module(policy)  # data parallel: identical weights and BatchNorm statistics on every rank
         self.opt = torch.optim.Adam(policy.parameters(), lr=cfg.lr)
         self.returns: List[float] = []
         self._ep_ret = torch.zeros(env.num_envs, dtype=torch.float64, device=env.device)
+        # Trajectory layout: with at least rollout_steps + 1 slots the environment writes the observation of step t
+        # straight into slot t + 1 of its [S, B, ...] tensors and the update reads them in place -- no observation
+        # byte is copied.  (With fewer slots every observation is copied once per step, as in round 1.)
+        self.in_place = getattr(env, "num_slots", 1) >= cfg.rollout_steps + 1
+        self.timing = {"collect_s": 0.0, "update_s": 0.0, "env_steps": 0}
 
     @torch.no_grad()
     def collect(self) -> Dict[str, torch.Tensor]:
         env, T, B = self.env, self.cfg.rollout_steps, self.env.num_envs
-        buf = {k: torch.zeros((T,) + tuple(env.obs[k].shape), dtype=env.obs[k].dtype, device=env.device) for k in self.obs_keys}
+        if self.in_place:
+            if env.slot != 0:  # the observation the last rollout ended on becomes slot 0 of this one (1 / T of the bytes)
+                for k in self.obs_keys:
+                    env.traj[k][0].copy_(env.traj[k][env.slot])
+                env.select_slot(0)
+            buf = {k: env.traj[k][:T] for k in self.obs_keys}  # views
+        else:
+            buf = {k: torch.zeros((T,) + tuple(env.obs[k].shape), dtype=env.obs[k].dtype, device=env.device) for k in self.obs_keys}
         act = torch.zeros((T, B), dtype=torch.int64, device=env.device)
         logp = torch.zeros((T, B), device=env.device)
         val = torch.zeros((T + 1, B), device=env.device)
@@ -66,12 +69,16 @@ class PPOTrainer:
         self.policy.eval()
         finished = []
         for t in range(T):
-            for k in self.obs_keys:
-                buf[k][t].copy_(env.obs[k])
-            logits, v = self.policy(env.obs)
+            obs = env.obs  # slot t
+            if not self.in_place:
+                for k in self.obs_keys:
+                    buf[k][t].copy_(obs[k])
+            logits, v = self.policy(obs)
             d = torch.distributions.Categorical(logits=logits)
             a = d.sample()
             act[t], logp[t], val[t] = a, d.log_prob(a), v
+            if self.in_place:
+                env.select_slot(t + 1)
             env.step(a.to(torch.int32))
             rew[t], done[t] = env.reward.float(), env.done.float()
             self._ep_ret += env.reward
@@ -97,7 +104,14 @@ class PPOTrainer:
         flat_obs = {k: v.reshape((N,) + tuple(v.shape[2:])) for k, v in batch["obs"].items()}
         act, logp0, ret = batch["act"].reshape(N), batch["logp"].reshape(N), batch["ret"].reshape(N)
         adv = normalize_advantages(batch["adv"].reshape(N), self.cfg.adv_mode)  # global mean / std over all ranks
-        self.policy.train()
+        # BatchNorm: the rollout computed logp0 with the running statistics, so the surrogate ratio must use them too
+        # (its first-epoch value is then exactly 1); the statistics themselves are refreshed once per iteration from
+        # a minibatch in training mode, averaged over the ranks.
+        with torch.no_grad():
+            self.policy.train()
+            self.policy({k: o[:max(1, N // self.cfg.minibatches)] for k, o in flat_obs.items()})
+            allreduce_mean_([b for b in self.policy.buffers()])
+        self.policy.eval()
         stats = {}
         for _ in range(self.cfg.epochs):
             perm = torch.randperm(N, device=act.device)
@@ -114,12 +128,23 @@ class PPOTrainer:
                 _allreduce_grads(self.policy)
                 torch.nn.utils.clip_grad_norm_(self.policy.parameters(), 1.0)
                 self.opt.step()
-                stats = {"loss": float(loss), "pg": float(pg), "vf": float(vf), "entropy": float(ent)}
+                stats = {"loss": float(loss.detach()), "pg": float(pg.detach()), "vf": float(vf.detach()), "entropy": float(ent.detach())}
         return stats
 
     def train(self, iterations: int, log=None):
+        import time
         for it in range(iterations):
-            stats = self.update(self.collect())
+            torch.cuda.synchronize(self.env.device)
+            t0 = time.perf_counter()
+            batch = self.collect()
+            torch.cuda.synchronize(self.env.device)
+            t1 = time.perf_counter()
+            stats = self.update(batch)
+            torch.cuda.synchronize(self.env.device)
+            t2 = time.perf_counter()
+            self.timing["collect_s"] += t1 - t0
+            self.timing["update_s"] += t2 - t1
+            self.timing["env_steps"] += self.cfg.rollout_steps * self.env.num_envs
             if log:
                 log(it, self.returns[-1] if self.returns else float("nan"), stats)
         return self.returns

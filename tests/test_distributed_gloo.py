@@ -61,6 +61,36 @@ def test_two_rank_gloo_advantage_normalisation_and_sharding():
     assert out[0]["h"] + out[1]["h"] == want  # the union of the shards is the single-process batch
 
 
+def _module_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pcbenv.distributed import allreduce_mean_, broadcast_module
+    torch.manual_seed(100 + rank)  # every rank builds DIFFERENT weights and BatchNorm statistics
+    net = torch.nn.Sequential(torch.nn.Conv2d(2, 3, 3), torch.nn.BatchNorm2d(3), torch.nn.ReLU(), torch.nn.Flatten(), torch.nn.Linear(3 * 4 * 4, 5))
+    net.train()
+    net(torch.randn(7, 2, 6, 6))  # moves the running statistics
+    before = torch.cat([t.detach().reshape(-1).float() for t in list(net.parameters()) + list(net.buffers())]).clone()
+    broadcast_module(net)
+    after = torch.cat([t.detach().reshape(-1).float() for t in list(net.parameters()) + list(net.buffers())])
+    grads = [torch.full((3,), float(rank + 1)), torch.full((2, 2), float(10 * (rank + 1)))]
+    allreduce_mean_(grads)
+    out[rank] = {"before": before.numpy(), "after": after.numpy(), "g0": grads[0].numpy(), "g1": grads[1].numpy()}
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_model_broadcast_and_gradient_mean():
+    """Data-parallel PPO starts every rank from rank 0's parameters AND buffers (BatchNorm running statistics) and
+    averages gradients with one flat all-reduce (pcbenv/ppo.py)."""
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_module_worker, args=(world, port, out), nprocs=world, join=True)
+    assert not np.array_equal(out[0]["before"], out[1]["before"])
+    assert np.array_equal(out[0]["after"], out[0]["before"]) and np.array_equal(out[1]["after"], out[0]["before"])
+    assert np.allclose(out[0]["g0"], 1.5) and np.allclose(out[1]["g0"], 1.5) and np.allclose(out[0]["g1"], 15.0)
+
+
 def test_single_process_normalisation():
     from pcbenv.distributed import normalize_advantages
     a = torch.arange(10, dtype=torch.float32)

@@ -13,24 +13,21 @@ sys.path.insert(0, os.path.join(REPO, "rl-environment-for-component-placement_am
 import torch  # noqa: E402
 from pcbenv import EnvConfig  # noqa: E402
 from pcbenv.batched_env import BatchedPlacementEnv  # noqa: E402
-from pcbenv.feeder import InstanceFeeder  # noqa: E402
 from pcbenv.policy import SpatialPolicy  # noqa: E402
 from pcbenv.ppo import PPOConfig, PPOTrainer  # noqa: E402
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 torch.manual_seed(0)
 cfg = EnvConfig.spatial(10, 10, 9, 9, 2, 2, 2, 2, 5, 5, 3, 3, 6, 6, "centroid", 2, 0.75)
-env = BatchedPlacementEnv(cfg, 1024, queue_depth=8, auto_reset=True)
-env.generate_instances()
+env = BatchedPlacementEnv(cfg, 1024, queue_depth=32, auto_reset=True, num_slots=11)  # trajectory layout: no observation copies
+env.enable_device_instances()  # a fresh instance for every episode, generated on the GPU
 env.reset()
 policy = SpatialPolicy(cfg).to(env.device)
 tr = PPOTrainer(env, policy, PPOConfig(rollout_steps=10, lr=1e-3))
 t0 = time.time()
 curve = []
-feeder = InstanceFeeder(env, prefetch=4)  # fresh instances for every episode, generated in the background
-tr.train(iters, log=lambda it, r, s: (curve.append(r), feeder.refill(),
-                              print(f"iter {it:3d} mean_return {r:8.4f} entropy {s['entropy']:.3f}", flush=True)))
-feeder.close()
+tr.train(iters, log=lambda it, r, s: (curve.append(r), print(f"iter {it:3d} mean_return {r:8.4f} entropy {s['entropy']:.3f}", flush=True)))
 out = {"config": "10x10 spatial, 5 comps 2x2, 3 nets x 6 pins, centroid", "envs": 1024, "iterations": iters,
-       "mean_return": curve, "first5": sum(curve[:5]) / 5, "last5": sum(curve[-5:]) / 5, "seconds": time.time() - t0, "episodes_per_env": env.queue_cursors()[0], "fresh_instances": True}
+       "mean_return": curve, "first5": sum(curve[:5]) / 5, "last5": sum(curve[-5:]) / 5, "seconds": time.time() - t0, "episodes_per_env": env.queue_cursors()[0], "fresh_instances": "on-device generator", "generator_errors": env.device_instance_errors(),
+       "observation_copies_per_step": 0 if tr.in_place else 1}
 print(json.dumps(out))

@@ -8,14 +8,21 @@ import os
 import shutil
 import sys
 
-R = sys.argv[1] if len(sys.argv) > 1 else "r1"
+R = sys.argv[1] if len(sys.argv) > 1 else "r2"
 src, dst = f"gpurun_out/{R}", f"profiles/{R}"
 os.makedirs(dst, exist_ok=True)
 for f in glob.glob(f"{src}/*_bench.json"):
     lines = [l for l in open(f) if l.startswith("{")]
     if lines:
         open(os.path.join(dst, os.path.basename(f)), "w").write(lines[-1])
-for cfg in ("c2", "c3", "c4", "c5"):
+for extra in ("c3_fresh", "c3_rollout"):
+    st = sorted(glob.glob(f"{src}/prof_{extra}/*/*kernel_stats.csv"), key=os.path.getmtime)
+    if st:
+        shutil.copy(st[-1], f"{dst}/{extra}_kernel_stats.csv")
+for f in ("stagger.txt",):
+    if os.path.exists(f"{src}/{f}"):
+        shutil.copy(f"{src}/{f}", f"{dst}/{f}")
+for cfg in ("c2", "c3", "c4", "c5", "c3_16384", "c3_65536", "c4_16384"):
     st = sorted(glob.glob(f"{src}/prof_{cfg}/*/*kernel_stats.csv"), key=os.path.getmtime)  # newest run
     if st:
         shutil.copy(st[-1], f"{dst}/{cfg}_kernel_stats.csv")
@@ -32,7 +39,9 @@ for cfg in ("c2", "c3", "c4", "c5"):
         w = out["WRITE_SIZE"]["mean_KiB"] * 1024
         r = out["FETCH_SIZE"]["mean_KiB"] * 1024 * 2
         bench = json.load(open(f"{dst}/{cfg}_bench.json"))
-        res = {"config": cfg, "kernel": "k_step (fused loop, auto-reset, full refresh)", "write_bytes_per_launch": w,
+        res = {"config": cfg, "kernel": "k_step (fused loop, auto-reset, full refresh, replayed queue)",
+               "envs": bench["config"]["envs_per_gpu"], "kernel_ms": bench["roofline"]["kernel_ms"],
+               "hbm_GBps_from_counters": (w + r) / (bench["roofline"]["kernel_ms"] * 1e-3) / 1e9, "write_bytes_per_launch": w,
                "fetch_bytes_per_launch_corrected_x2": r, "hbm_bytes_per_launch": w + r,
                "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_env_step"] * bench["roofline"]["units_per_launch"],
                "counters": out,

@@ -130,8 +130,8 @@ __device__ inline void transition(const DevParams &p, Lds &l, int e, int row, in
 }
 
 // The step kernel.  TRAJ = false is the lean build for the in-place layout and one transition per launch (num_slots
-// == 1 and num_steps == 1 are then compile-time facts: no step loop, no whole-tensor feature emission -- 40 fewer
-// VGPRs); TRAJ = true serves the trajectory layout and the persistent rollout.  num_steps == 1: one transition with the given (or, `sampled`, a uniformly drawn legal) action.
+// == 1 and num_steps == 1 are then compile-time facts: no step loop, no whole-tensor feature emission -- 84 instead
+// of 112-121 VGPRs); TRAJ = true serves the trajectory layout and the persistent rollout.  num_steps == 1: one transition with the given (or, `sampled`, a uniformly drawn legal) action.
 // num_steps > 1 (sampled only) is the persistent rollout: num_steps transitions of environment e in ONE launch
 // (step t draws with step_index + t, exactly what k_sample or a single-step launch would draw).  The state block
 // stays in LDS for the whole rollout -- no reload / write-back, no launch latency per step, and the wavefronts
@@ -139,9 +139,10 @@ __device__ inline void transition(const DevParams &p, Lds &l, int e, int row, in
 // of the whole batch.  Step t writes its outputs into slot (slot + t) % num_slots of the bound [num_slots, B, ...]
 // tensors and its action into actions[t].
 template <int KIND, int WW, int NW, bool ROUTES, bool STREAM, bool TRAJ>
-// The lean build is held to 72 VGPRs (7 wavefronts per SIMD): what does not fit is spilled inside the rarely run
-// routing reward, not in the per-step stream.
-__global__ __attribute__((amdgpu_waves_per_eu(TRAJ ? 4 : 7, 8))) __launch_bounds__(64 * NW) void k_step(DevParams p, int *__restrict__ actions, int fmt, int sampled,
+// Four wavefronts per SIMD (16 one-wavefront workgroups per CU) is all a launch of up to ~4 workgroups per SIMD needs and
+// what LDS allows anyway; holding the lean build to 72 VGPRs for 7 wavefronts (spills inside the routing reward and one
+// at entry) measured 2-5 % slower at every batch size, so both builds may use up to 128.
+__global__ __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(64 * NW) void k_step(DevParams p, int *__restrict__ actions, int fmt, int sampled,
                                                u64 seed, u64 first_env, u64 step_index, int num_steps_) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (!TRAJ) p.stream_stores = STREAM;  // the launch's choice as a compile-time constant: only one store policy is compiled in

@@ -16,13 +16,13 @@
 //   CPython MT19937 seeded by init_by_array([seed]); choice(seq) = seq[_randbelow(len)] with
 //           getrandbits(k) = genrand_uint32() >> (32 - k)
 //
-// Execution model: one wavefront per environment, and the generator -- an inherently serial program of a few
-// thousand dependent steps -- is executed UNIFORMLY by all 64 lanes (every lane computes the same values; LDS
-// writes come from lane 0).  That keeps every table in LDS (both MT19937 states, the component / net / cell
-// lists, the record under construction) instead of per-lane scratch memory, whose ~1 us accesses made a
-// lane-per-environment version no faster than the host generator, and it lets the few data-parallel pieces use the
-// lanes: the block regeneration of MT19937 (624 words in ten 64-lane steps), the stable sort of the components by
-// free space (rank sort), list.remove(), the zero fill and the copy-out of the record.
+// Execution model: the generator is an inherently serial program of a few thousand dependent steps per record.  A
+// GROUP of G lanes (16, 32 or 64: as many as the configuration has components / nets, a quarter of its pins) serves
+// one environment and executes that program UNIFORMLY (every lane of the group computes the same scalars), 64 / G
+// environments per wavefront side by side.  That keeps every table in registers (one element per group lane) or LDS
+// instead of per-lane scratch memory, whose ~1 us accesses made a lane-per-environment version no faster than the
+// host generator, and it lets the data-parallel pieces use the group's lanes: the block regeneration of MT19937,
+// the stable sort of the components by free space (rank sort + permute), scans, list.remove(), the copy-out.
 // exp / log come from the device math library: like the host twin's libm they may differ from NumPy's SIMD
 // kernels in the last bit of a probability, which can change a table only if a uniform variate lands within
 // ~1 ulp of a threshold (~1e-15 per draw; see instance_gen.cpp).
@@ -40,20 +40,14 @@ struct GenState {            // per environment, in HBM
 #endif
 };
 #ifdef GEN_STAMPS
-#define GSTAMP(k) do { if (lane == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g->stamps[k] = t_; } } while (0)
+#define GSTAMP(k) do { if ((lane & (G - 1)) == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g->stamps[k] = t_; } } while (0)
 #else
 #define GSTAMP(k) do { } while (0)
 #endif
 #define GEN_REC_MAX (16 + 8 * (PCBENV_MAX_COMPONENTS + PCBENV_MAX_PINS))
-// One wavefront's LDS: ONE generator at a time and the record under construction.  NumPy's state serves steps 1-9
-// of a record, CPython's step 10; they are swapped through HBM in between (2.5 KB each way, coalesced) so that the
-// generator's wavefronts fit into the LDS the step kernel's workgroups leave free (of `rec` only instStride bytes
-// are allocated: the block is dynamic shared memory).
-struct GenLds {
-    unsigned mt[624];
-    unsigned long long rec[GEN_REC_MAX / 8];
-};
-#define GEN_LDS_BYTES(instStride) (624 * 4 + (int)(instStride))
+// A group's LDS holds ONE generator state at a time and the record under construction: NumPy's state serves steps
+// 1-9 of a record, CPython's step 10; they are swapped through HBM in between (2.5 KB each way, coalesced) so that the
+// generator's wavefronts fit into the LDS the step kernel's workgroups leave free.
 #define GEN_MAX_GRID 2048
 
 struct GenParams {           // by value kernel argument
@@ -70,15 +64,45 @@ struct GenParams {           // by value kernel argument
 // LDS-qualified pointers: the accesses compile to ds_* instructions with 32-bit addresses (generic pointers would be
 // 64-bit flat accesses, and the kernel would live in spilled address registers)
 #define LDS3 __attribute__((address_space(3)))
-typedef volatile LDS3 GenLds *GenLdsPtr;
 typedef volatile LDS3 unsigned *LdsU32;
 typedef volatile LDS3 int *LdsI32;
 typedef volatile LDS3 unsigned long long *LdsU64;
 
-// ---- MT19937 in LDS: block regeneration by the whole wavefront, words handed out one by one --------------------
-__device__ inline void mt_regenerate(LdsU32 mt, int lane) {  // mt19937ar.c genrand_int32's refill, 64 words per step
-    for (int base = 0; base < 624; base += WAVE) {
-        const int kk = base + lane;
+// ---- G lanes per environment ------------------------------------------------------------------------------------
+// A wavefront generates 64 / G records at once: environment `lane / G` of its batch lives in the G lanes of its
+// group, and everything below that says "uniform" means uniform WITHIN A GROUP.  G = 16 is possible when a
+// configuration has at most 16 components, 16 nets and 64 pins (c3, c4), 32 up to 32 / 32 / 128 (c5); the shipped
+// choice is G = 64 for every configuration (gen_group_lanes below: the packed builds measured slower).  Groups diverge freely (different loop counts); every cross-lane operation
+// stays inside a group: v_readlane becomes ds_bpermute (per-lane source), the scans stop at the group width, ballots
+// are shifted and masked to the group.
+template <int G> __device__ inline int grl(int v, int idx, int lane) {
+    if (G == WAVE) return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(idx));
+    return __builtin_amdgcn_ds_bpermute(((lane & ~(G - 1)) | idx) << 2, v);
+}
+template <int G> __device__ inline double grl(double v, int idx, int lane) {
+    return __hiloint2double(grl<G>(__double2hiint(v), idx, lane), grl<G>(__double2loint(v), idx, lane));
+}
+template <int G> __device__ inline int gscan(int x, int lane) {  // inclusive prefix sum inside the group (DPP)
+    const int row = lane & 15;
+    int t;
+    t = __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false); if (row >= 1) x += t;   // row_shr:1
+    t = __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false); if (row >= 2) x += t;   // row_shr:2
+    t = __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false); if (row >= 4) x += t;   // row_shr:4
+    t = __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false); if (row >= 8) x += t;   // row_shr:8
+    if (G >= 32) { t = __builtin_amdgcn_update_dpp(0, x, 0x142, 0xF, 0xF, false); if ((lane & 31) >= 16) x += t; }  // row_bcast:15
+    if (G == 64) { t = __builtin_amdgcn_update_dpp(0, x, 0x143, 0xF, 0xF, false); if (lane >= 32) x += t; }         // row_bcast:31
+    return x;
+}
+template <int G> __device__ inline u64 gballot(bool pred, int lane) {  // the group's bits of the ballot, at bit 0
+    const u64 b = __ballot(pred);
+    if (G == WAVE) return b;
+    return (b >> (lane & ~(G - 1))) & ((1ull << G) - 1ull);
+}
+
+// ---- MT19937 in LDS: block regeneration by the G lanes of the group, words handed out one by one -----------------
+template <int G> __device__ inline void mt_regenerate(LdsU32 mt, int gl) {  // mt19937ar.c genrand_int32's refill, G words per step
+    for (int base = 0; base < 624; base += G) {
+        const int kk = base + gl;
         unsigned v = 0;
         if (kk < 624) {  // mt[kk + 1] is still the old word (its owner writes after this read), mt[kk + 397 - 624] already the new one
             const int k1 = kk + 1 == 624 ? 0 : kk + 1, km = kk + 397 >= 624 ? kk + 397 - 624 : kk + 397;
@@ -90,42 +114,46 @@ __device__ inline void mt_regenerate(LdsU32 mt, int lane) {  // mt19937ar.c genr
         __builtin_amdgcn_wave_barrier();
     }
 }
-// One generator state between HBM and LDS: all ten loads of a lane go out together, then the stores (through the
-// volatile LDS pointer every element would otherwise wait for the one before: 10 x a memory round trip per copy).
-__device__ inline void mt_to_lds(LdsU32 dst, const unsigned *src, int lane) {
-    unsigned t[10];
-    #pragma unroll
-    for (int r = 0; r < 10; r++) t[r] = r * WAVE + lane < 624 ? src[r * WAVE + lane] : 0u;
-    #pragma unroll
-    for (int r = 0; r < 10; r++) if (r * WAVE + lane < 624) dst[r * WAVE + lane] = t[r];
+// One generator state between HBM and LDS, ten words of a lane in flight at a time (through the volatile LDS pointer
+// every element would otherwise wait for the one before).
+template <int G> __device__ inline void mt_to_lds(LdsU32 dst, const unsigned *src, int gl) {
+    for (int b0 = 0; b0 < 624; b0 += 10 * G) {
+        unsigned t[10];
+        #pragma unroll
+        for (int r = 0; r < 10; r++) t[r] = b0 + r * G + gl < 624 ? src[b0 + r * G + gl] : 0u;
+        #pragma unroll
+        for (int r = 0; r < 10; r++) if (b0 + r * G + gl < 624) dst[b0 + r * G + gl] = t[r];
+    }
 }
-__device__ inline void mt_from_lds(unsigned *dst, LdsU32 src, int lane) {
-    unsigned t[10];
-    #pragma unroll
-    for (int r = 0; r < 10; r++) t[r] = r * WAVE + lane < 624 ? src[r * WAVE + lane] : 0u;
-    #pragma unroll
-    for (int r = 0; r < 10; r++) if (r * WAVE + lane < 624) dst[r * WAVE + lane] = t[r];
+template <int G> __device__ inline void mt_from_lds(unsigned *dst, LdsU32 src, int gl) {
+    for (int b0 = 0; b0 < 624; b0 += 10 * G) {
+        unsigned t[10];
+        #pragma unroll
+        for (int r = 0; r < 10; r++) t[r] = b0 + r * G + gl < 624 ? src[b0 + r * G + gl] : 0u;
+        #pragma unroll
+        for (int r = 0; r < 10; r++) if (b0 + r * G + gl < 624) dst[b0 + r * G + gl] = t[r];
+    }
 }
-
-// The stream of tempered words, 64 at a time in a register (lane i holds word base + i): a draw is one v_readlane
-// instead of an LDS round trip.
-struct MtReader {
+// The stream of tempered words, G at a time in a register (group lane i holds word base + i): a draw is one
+// cross-lane read instead of an LDS round trip.
+template <int G> struct MtReader {
     LdsU32 mt;
     int pos;        // words of the current block already handed out (624 = regenerate first)
     int base;       // first word index held in `cache`; -1 = none
     unsigned cache;
     __device__ unsigned next(int lane) {
-        if (pos >= 624) { mt_regenerate(mt, lane); pos = 0; base = -1; }  // wave-uniform
-        if (base < 0 || pos >= base + WAVE) {
+        const int gl = lane & (G - 1);
+        if (pos >= 624) { mt_regenerate<G>(mt, gl); pos = 0; base = -1; }
+        if (base < 0 || pos >= base + G) {
             base = pos;
-            unsigned v = base + lane < 624 ? mt[base + lane] : 0u;
+            unsigned v = base + gl < 624 ? mt[base + gl] : 0u;
             v ^= (v >> 11);
             v ^= (v << 7) & 0x9d2c5680u;
             v ^= (v << 15) & 0xefc60000u;
             v ^= (v >> 18);
             cache = v;
         }
-        const unsigned out = (unsigned)__builtin_amdgcn_readlane((int)cache, __builtin_amdgcn_readfirstlane(pos - base));
+        const unsigned out = (unsigned)grl<G>((int)cache, pos - base, lane);
         pos++;
         return out;
     }
@@ -151,17 +179,12 @@ __device__ inline void mt_init_by_array(unsigned *mt, const unsigned *key, int l
     mt[0] = 0x80000000u;
 }
 
-// All of the below runs wave-uniformly: every lane holds the same scalars.  Small tables live one element per lane in
-// registers (free space and id of the component at each sorted position, net probabilities, counts, the remaining
-// cells of a component, the pin records) and are read with v_readlane / permutes; LDS holds the two generators and
-// the record under construction.
-__device__ inline int rl(int v, int idx) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(idx)); }
-__device__ inline double rl(double v, int idx) {
-    const int i = __builtin_amdgcn_readfirstlane(idx);
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), i), __builtin_amdgcn_readlane(__double2loint(v), i));
-}
-struct NpStream {  // NumPy legacy RandomState pieces
-    MtReader rd;
+// All of the below runs uniformly within a group: every lane of the group holds the same scalars.  Small tables live
+// one element per group lane in registers (free space and id of the component at each sorted position, net
+// probabilities, counts, the pin records) and are read with cross-lane reads / permutes; LDS holds one generator
+// state, the record under construction and the cell list of step 10, per group.
+template <int G> struct NpStream {  // NumPy legacy RandomState pieces
+    MtReader<G> rd;
     int lane, has_gauss;
     double gauss;
     __device__ unsigned u32() { return rd.next(lane); }
@@ -205,75 +228,81 @@ struct NpStream {  // NumPy legacy RandomState pieces
         }
         return X;
     }
-    // RandomState.multinomial(n, p[0..d)), p one element per lane -> the count of bin `lane`.  The chain of legacy
-    // binomials is sequential, but everything that does not depend on the draws -- the running remainder Sum, the
-    // conditional probabilities p[j] / Sum, which tail the inversion works on and its log(q) -- is evaluated for all
-    // bins at once first (the same operations on the same operands as numpy's loop).
+    // RandomState.multinomial(n, p[0..d)), p one element per group lane -> the count of bin `gl`.  The chain of
+    // legacy binomials is sequential, but everything that does not depend on the draws -- the running remainder Sum,
+    // the conditional probabilities p[j] / Sum, which tail the inversion works on and its log(q) -- is evaluated for
+    // all bins at once first (the same operations on the same operands as numpy's loop).
     __device__ int multinomial(int n, double p_l, int d, bool *ok) {
+        const int gl = lane & (G - 1);
         double Sum = 1.0, sum_l = 1.0;
-        for (int j = 0; j < d - 1; j++) { if (lane == j) sum_l = Sum; Sum -= rl(p_l, j); }
+        for (int j = 0; j < d - 1; j++) { if (gl == j) sum_l = Sum; Sum -= grl<G>(p_l, j, lane); }
         const double P_l = p_l / sum_l;                      // random_binomial(p = P_l, n = what is left)
         const bool upper_l = !(P_l <= 0.5);                  // p > 0.5: draw the complement with q = 1 - p
         const double pp_l = upper_l ? 1.0 - P_l : P_l, qq_l = 1.0 - pp_l, lg_l = log(qq_l);
         int cnt_l = 0;
         int dn = n;
         for (int j = 0; j < d - 1; j++) {
-            const double P = rl(P_l, j);
+            const double P = grl<G>(P_l, j, lane);
             int x = 0;
             if (dn != 0 && P != 0.0) {
-                const double pp = rl(pp_l, j);
+                const double pp = grl<G>(pp_l, j, lane);
                 if (!(pp * (double)dn <= 30.0)) { *ok = false; return cnt_l; }  // BTPE would be needed: outside the sizes this library supports
-                x = binomial_inversion(dn, pp, rl(qq_l, j), rl(lg_l, j));
-                if (rl((int)upper_l, j)) x = dn - x;
+                x = binomial_inversion(dn, pp, grl<G>(qq_l, j, lane), grl<G>(lg_l, j, lane));
+                if (grl<G>((int)upper_l, j, lane)) x = dn - x;
             }
-            if (lane == j) cnt_l = x;
+            if (gl == j) cnt_l = x;
             dn -= x;
             if (dn <= 0) break;
         }
-        if (dn > 0 && lane == d - 1) cnt_l = dn;
+        if (dn > 0 && gl == d - 1) cnt_l = dn;
         return cnt_l;
     }
 };
 
-// np.sum of a float64 array held one element per lane (pairwise summation with 8 accumulators, block 128 -- n <= 64 here)
-__device__ inline double np_sum_lanes(double a_l, int n) {
+// np.sum of a float64 array held one element per group lane (pairwise summation with 8 accumulators, block 128 -- n <= 64 here)
+template <int G> __device__ inline double np_sum_lanes(double a_l, int n, int lane) {
     if (n < 8) {
         double r = 0.0;
-        for (int i = 0; i < n; i++) r += rl(a_l, i);
+        for (int i = 0; i < n; i++) r += grl<G>(a_l, i, lane);
         return r;
     }
     double r[8];
     #pragma unroll
-    for (int j = 0; j < 8; j++) r[j] = rl(a_l, j);
+    for (int j = 0; j < 8; j++) r[j] = grl<G>(a_l, j, lane);
     int i;
     for (i = 8; i < n - (n % 8); i += 8) {
         #pragma unroll
-        for (int j = 0; j < 8; j++) r[j] += rl(a_l, i + j);
+        for (int j = 0; j < 8; j++) r[j] += grl<G>(a_l, i + j, lane);
     }
     double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-    for (; i < n; i++) res += rl(a_l, i);
+    for (; i < n; i++) res += grl<G>(a_l, i, lane);
     return res;
 }
 
-// One record of the environment's stream into L->rec (wire format of include/pcbenv.h).  Wave-uniform.
-__device__ inline int gen_record(const GenParams &c, GenLdsPtr L, GenState *g, NpStream &rs, int &py_pos_, int lane) {
+// The group's LDS: one generator state, the record, the cell list of step 10.
+struct GrpLds { LdsU32 mt; LdsU64 rec; volatile LDS3 unsigned char *cells; };
+#define GEN_GROUP_LDS_BYTES(instStride) (624 * 4 + (int)(instStride) + PCBENV_MAX_PINS_PER_COMPONENT)
+
+// One record of the group's stream into L.rec (wire format of include/pcbenv.h).  Uniform within the group.
+template <int G> __device__ inline int gen_record(const GenParams &c, const GrpLds &L, GenState *g, NpStream<G> &rs, int &py_pos_, int lane) {
+    const int gl = lane & (G - 1), gbase = lane & ~(G - 1);
     const int words = (int)(c.instStride / 8);
     GSTAMP(0);
-    for (int i = lane; i < words; i += WAVE) L->rec[i] = 0ull;
-    LdsI32 hdr = (LdsI32)L->rec;
-    LdsU64 crec = L->rec + 2, prec = crec + c.C;
-    // steps 1-2: lane i keeps component i (h | w << 8); a_s / ord = free space and id of the component at sorted position `lane`
+    for (int i = gl; i < words; i += G) L.rec[i] = 0ull;
+    LdsI32 hdr = (LdsI32)L.rec;
+    LdsU64 crec = L.rec + 2, prec = crec + c.C;
+    // steps 1-2: group lane i keeps component i (h | w << 8); a_s / ord = free space and id of the component at sorted position `gl`
     const int ncomp = rs.randint(c.min_comp, c.max_comp + 1);
-    int total_area = 0, hw_l = 0, a_s = -1, ord = lane;
+    int total_area = 0, hw_l = 0, a_s = -1, ord = gl;
     for (int i = 0; i < ncomp; i++) {
         const int h = rs.randint(c.min_h, c.max_h + 1);
         const int w = rs.randint(c.min_w, c.max_w + 1);
-        if (lane == i) { hw_l = h | (w << 8); a_s = h * w; }
+        if (gl == i) { hw_l = h | (w << 8); a_s = h * w; }
         total_area += h * w;
     }
     GSTAMP(1);
-    if (lane < ncomp) crec[lane] = (unsigned long long)hw_l;
-    if (lane == 0) hdr[0] = ncomp;
+    if (gl < ncomp) crec[gl] = (unsigned long long)hw_l;
+    if (gl == 0) hdr[0] = ncomp;
     if (c.kind == PCBENV_RECT) return PCBENV_OK;
     // steps 3-4
     int nn = rs.randint(c.min_nets, c.max_nets + 1);
@@ -281,14 +310,14 @@ __device__ inline int gen_record(const GenParams &c, GenLdsPtr L, GenState *g, N
     int total = rs.randint(c.min_ppn * nn, c.max_ppn * nn + 1);
     if (total > total_area) total = total_area;
     if (nn < 1 || total > c.P || c.min_ppn * nn > total) return PCBENV_EINVAL;  // the reference raises here
-    // step 5: softmax of normal samples (drawn even when unused); lane i keeps net i
+    // step 5: softmax of normal samples (drawn even when unused); group lane i keeps net i
     double pr_l = 0.0;
     for (int i = 0; i < nn; i++) {
         const double z = (1.0 / (double)nn) + (1.0 / (double)(c.net_distribution + 1)) * rs.legacy_gauss();
-        if (lane == i) pr_l = z;
+        if (gl == i) pr_l = z;
     }
     pr_l = exp(pr_l);
-    const double sez = np_sum_lanes(pr_l, nn);
+    const double sez = np_sum_lanes<G>(pr_l, nn, lane);
     pr_l = pr_l / sez;
     GSTAMP(2);
     // steps 6-7: creation ids -> nets
@@ -300,7 +329,7 @@ __device__ inline int gen_record(const GenParams &c, GenLdsPtr L, GenState *g, N
         const int k = min(c.max_ppn - lo, rem);
         for (int t = 0; t < rem; t++) {
             double q_l = pr_l * (extra_l < k ? 1.0 : 0.0);
-            const double sq = np_sum_lanes(q_l, nn);
+            const double sq = np_sum_lanes<G>(q_l, nn, lane);
             q_l = q_l / sq;
             extra_l += rs.multinomial(1, q_l, nn, &ok);
             if (!ok) return PCBENV_ELIMIT;
@@ -314,36 +343,36 @@ __device__ inline int gen_record(const GenParams &c, GenLdsPtr L, GenState *g, N
     // step 9: net by net in net order; the components stay sorted by free space (descending, stable) from net to net
     int q_idx = 0, id_cursor = lo * nn;  // first output pin of the net; first creation id of the net's extra pins
     for (int n = 0; n < nn; n++) {
-        const int extra_n = rl(extra_l, n);
+        const int extra_n = grl<G>(extra_l, n, lane);
         int unassigned = lo + extra_n;
         {   // stable sort of the positions by free space: rank = how many must precede this one, then one permute
             int rank = 0;
             for (int j = 0; j < ncomp; j++) {
-                const int aj = rl(a_s, j);
-                rank += (aj > a_s) | ((aj == a_s) & (j < lane));
+                const int aj = grl<G>(a_s, j, lane);
+                rank += (aj > a_s) | ((aj == a_s) & (j < gl));
             }
-            if (lane >= ncomp) rank = lane;
-            a_s = __builtin_amdgcn_ds_permute(rank << 2, a_s);
-            ord = __builtin_amdgcn_ds_permute(rank << 2, ord);
+            if (gl >= ncomp) rank = gl;
+            a_s = __builtin_amdgcn_ds_permute((gbase + rank) << 2, a_s);
+            ord = __builtin_amdgcn_ds_permute((gbase + rank) << 2, ord);
         }
         int k;
         {   // the first k >= kcomp positions with enough room for the net (the reference grows k one by one)
-            const int cum = wave_inclusive_scan(lane < ncomp ? a_s : 0, lane);
-            const u64 enough = __ballot(lane >= kcomp - 1 && lane < ncomp && cum >= unassigned);
+            const int cum = gscan<G>(gl < ncomp ? a_s : 0, lane);
+            const u64 enough = gballot<G>(gl >= kcomp - 1 && gl < ncomp && cum >= unassigned, lane);
             if (!enough) return PCBENV_EINVAL;
             k = __ffsll((long long)enough);
         }
         int pin_in_net = 0;
         while (unassigned > 0) {
-            const int cum = wave_inclusive_scan(lane < k ? a_s : 0, lane);
-            const int tot = rl(cum, k - 1);
+            const int cum = gscan<G>(gl < k ? a_s : 0, lane);
+            const int tot = grl<G>(cum, k - 1, lane);
             const double prob_l = (double)a_s / (double)tot;
             const int cnt_l = rs.multinomial(unassigned, prob_l, k, &ok);
             if (!ok) return PCBENV_ELIMIT;
-            const int m_l = lane < k ? min(cnt_l, a_s) : 0;
+            const int m_l = gl < k ? min(cnt_l, a_s) : 0;
             a_s -= m_l;
-            const int incl = wave_inclusive_scan(m_l, lane);
-            const int assigned = rl(incl, WAVE - 1);
+            const int incl = gscan<G>(m_l, lane);
+            const int assigned = grl<G>(incl, G - 1, lane);
             for (int t = 0; t < m_l; t++) {
                 // creation id of the pi-th pin of net n (spatial); index in this batch (pin env, quirk Q1)
                 const int pi = pin_in_net + incl - m_l + t;
@@ -358,25 +387,24 @@ __device__ inline int gen_record(const GenParams &c, GenLdsPtr L, GenState *g, N
     }
     GSTAMP(4);
     // NumPy's generator leaves LDS, CPython's comes in
-    mt_from_lds(g->np_mt, L->mt, lane);
-    mt_to_lds(L->mt, g->py_mt, lane);
+    mt_from_lds<G>(g->np_mt, L.mt, gl);
+    mt_to_lds<G>(L.mt, g->py_mt, gl);
     GSTAMP(5);
     rs.rd.base = -1;  // (the words in LDS are CPython's now; NumPy's come back with the next record)
-    MtReader py{L->mt, py_pos_, -1, 0u};
-    // step 10: per component, random.choice over the remaining cells (row-major), pins in self.pins order.  Lane j of
-    // chunk c keeps pin 64 c + j; a component's pins are a ballot; the cell list lives one cell per lane.
-    unsigned long long rec_r[PCBENV_MAX_PINS / WAVE];
+    MtReader<G> py{L.mt, py_pos_, -1, 0u};
+    // step 10: per component, random.choice over the remaining cells (row-major), pins in self.pins order.  Group lane j of
+    // chunk ch keeps pin G ch + j (total <= 4 G); a component's pins are a ballot; the cell list is in LDS.
+    unsigned long long rec_r[4];
     #pragma unroll
-    for (int ch = 0; ch < PCBENV_MAX_PINS / WAVE; ch++) rec_r[ch] = ch * WAVE + lane < total ? prec[ch * WAVE + lane] : ~0ull;
+    for (int ch = 0; ch < 4; ch++) rec_r[ch] = ch * G + gl < total ? prec[ch * G + gl] : ~0ull;
     for (int cid = 0; cid < ncomp; cid++) {
-        const int hw = rl(hw_l, cid), w = hw >> 8;
+        const int hw = grl<G>(hw_l, cid, lane), w = hw >> 8;
         int ncell = (hw & 0xFF) * w;
         const unsigned wmagic = (65536u + (unsigned)w - 1u) / (unsigned)w;  // cell / w == (cell * wmagic) >> 16 for cell < 4160, w <= 16
-        int cells_l = lane;
+        for (int i = gl; i < ncell; i += G) L.cells[i] = (unsigned char)i;
         #pragma unroll
-        for (int ch = 0; ch < PCBENV_MAX_PINS / WAVE; ch++) {
-            if (ch * WAVE >= total) break;
-            u64 mine = __ballot((int)((rec_r[ch] >> 24) & 0xFF) == cid && rec_r[ch] != ~0ull);
+        for (int ch = 0; ch < 4; ch++) {
+            u64 mine = gballot<G>((int)((rec_r[ch] >> 24) & 0xFF) == cid && rec_r[ch] != ~0ull, lane);
             while (mine) {
                 const int jl = __ffsll((long long)mine) - 1;
                 mine &= mine - 1;
@@ -384,20 +412,25 @@ __device__ inline int gen_record(const GenParams &c, GenLdsPtr L, GenState *g, N
                 for (int v = ncell; v; v >>= 1) kbits++;
                 unsigned r;
                 do { r = py.next(lane) >> (32 - kbits); } while ((int)r >= ncell);  // _randbelow_with_getrandbits
-                const int cell = rl(cells_l, (int)r);
-                const int nxt = __shfl_down(cells_l, 1);
-                if (lane >= (int)r) cells_l = nxt;  // list.remove(value): cells are unique
+                const int cell = L.cells[r];
+                for (int t0 = (int)r; t0 + 1 < ncell; t0 += G) {  // list.remove(value): cells are unique; G cells per step, ascending
+                    const int t = t0 + gl;
+                    const unsigned char nxt = t + 1 < ncell ? L.cells[t + 1] : (unsigned char)0;
+                    __builtin_amdgcn_wave_barrier();
+                    if (t + 1 < ncell) L.cells[t] = nxt;
+                    __builtin_amdgcn_wave_barrier();
+                }
                 ncell--;
                 const unsigned cx = ((unsigned)cell * wmagic) >> 16, cy = (unsigned)cell - cx * (unsigned)w;
-                if (lane == jl) rec_r[ch] |= (unsigned long long)cx | ((unsigned long long)cy << 8);
+                if (gl == jl) rec_r[ch] |= (unsigned long long)cx | ((unsigned long long)cy << 8);
             }
         }
     }
     GSTAMP(6);
     #pragma unroll
-    for (int ch = 0; ch < PCBENV_MAX_PINS / WAVE; ch++) if (ch * WAVE + lane < total) prec[ch * WAVE + lane] = rec_r[ch];
-    if (lane == 0) { hdr[1] = nn; hdr[2] = total; }
-    mt_from_lds(g->py_mt, L->mt, lane);
+    for (int ch = 0; ch < 4; ch++) if (ch * G + gl < total) prec[ch * G + gl] = rec_r[ch];
+    if (gl == 0) { hdr[1] = nn; hdr[2] = total; }
+    mt_from_lds<G>(g->py_mt, L.mt, gl);
     GSTAMP(7);
     py_pos_ = py.pos;
     return PCBENV_OK;
@@ -416,36 +449,57 @@ __global__ __launch_bounds__(WAVE) void k_gen_seed(GenParams c, const unsigned *
     c.produced[e] = load_agent(c.cursor_pub + e);
 }
 
-// Tops up the queue of environment blockIdx.x (one wavefront): records produced[e] .. cursor + Q - 1 (slot = index
-// % Q), never overwriting a record the environment has not consumed (the published cursor can only be behind the
-// truth).  The records leave this XCD's L2 with the release fence at the end; the step kernels read them with
-// agent-scope loads.
+// Tops up the queues: group `lane / G` of a wavefront serves one environment at a time -- records produced[e] ..
+// cursor + Q - 1 (slot = index % Q), never overwriting a record the environment has not consumed (the published cursor
+// can only be behind the truth).  The records leave this XCD's L2 with the release fence at the end; the step kernels
+// read them with agent-scope loads.  The grid is capped (GEN_MAX_GRID): a wavefront walks over several batches of
+// environments, so that the generator never holds more than a few wavefront slots per CU next to the step kernels.
+template <int G>
 __global__ __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(WAVE) void k_gen_fill(GenParams c) {
     extern __shared__ __attribute__((aligned(16))) unsigned char gen_smem[];
-    GenLdsPtr L = (GenLdsPtr)gen_smem;
-    const int lane = threadIdx.x;
+    constexpr int EPW = WAVE / G;
+    const int lane = threadIdx.x, grp = lane / G, gl = lane & (G - 1);
     const int words = (int)(c.instStride / 8);
-    // The grid is capped (GEN_MAX_GRID): a wavefront walks over several environments, so that the generator never
-    // holds more than a few wavefront slots per CU while the step kernels run next to it.
-    for (int e = blockIdx.x; e < c.B; e += gridDim.x) {
+    const int per_group = (GEN_GROUP_LDS_BYTES(c.instStride) + 15) & ~15;
+    GrpLds L;
+    L.mt = (LdsU32)(gen_smem + grp * per_group);
+    L.rec = (LdsU64)(gen_smem + grp * per_group + 624 * 4);
+    L.cells = (volatile LDS3 unsigned char *)(gen_smem + grp * per_group + 624 * 4 + c.instStride);
+    for (int e0 = blockIdx.x * EPW; e0 < c.B; e0 += gridDim.x * EPW) {
+        const int e = e0 + grp;
+        if (e >= c.B) continue;
         GenState *g = c.gen + e;
         const unsigned cursor = load_agent(c.cursor_pub + e);
         unsigned produced = c.produced[e];
         if (produced - cursor >= (unsigned)c.Q || g->status != 0) continue;  // nothing to do: the common case
-        NpStream rs{MtReader{L->mt, g->np_pos, -1, 0u}, lane, g->has_gauss, g->gauss};
+        NpStream<G> rs{MtReader<G>{L.mt, g->np_pos, -1, 0u}, lane, g->has_gauss, g->gauss};
         int py_pos = g->py_pos, status = 0;
         while (produced - cursor < (unsigned)c.Q) {
-            mt_to_lds(L->mt, g->np_mt, lane);
+            mt_to_lds<G>(L.mt, g->np_mt, gl);
             rs.rd.base = -1;
-            status = gen_record(c, L, g, rs, py_pos, lane);
+            status = gen_record<G>(c, L, g, rs, py_pos, lane);
             if (status != PCBENV_OK) break;  // (the stream stops here; its state is not needed any more)
             unsigned long long *dst = (unsigned long long *)(c.queue + ((size_t)(produced % (unsigned)c.Q) * c.B + e) * c.instStride);
-            for (int i = lane; i < words; i += WAVE) dst[i] = L->rec[i];
+            for (int i = gl; i < words; i += G) dst[i] = L.rec[i];
             produced++;
-            if (c.kind == PCBENV_RECT) mt_from_lds(g->np_mt, L->mt, lane);  // (the others swapped it out before step 10)
+            if (c.kind == PCBENV_RECT) mt_from_lds<G>(g->np_mt, L.mt, gl);  // (the others swapped it out before step 10)
         }
-        if (lane == 0) { g->np_pos = rs.rd.pos; g->py_pos = py_pos; g->has_gauss = rs.has_gauss; g->gauss = rs.gauss; g->status = status; }
+        if (gl == 0) { g->np_pos = rs.rd.pos; g->py_pos = py_pos; g->has_gauss = rs.has_gauss; g->gauss = rs.gauss; g->status = status; }
         __threadfence();  // the records before the count
-        if (lane == 0) c.produced[e] = produced;
+        if (gl == 0) c.produced[e] = produced;
     }
 }
+// lanes per environment for a configuration (see above); LDS bytes of a refill launch
+// Measured (tools/gen_harness.hip, idle MI355X, c3 / c4 records): G = 64: 101-103 us per record per wavefront; G = 32: ~1 000 us
+// and G = 16: ~500 us per record per group, i.e. 121-250 us per record per wavefront -- the cross-lane reads that are a
+// v_readlane at G = 64 become ds_bpermute round trips inside the dependent chain, which costs more than packing gains.
+// So every configuration runs one environment per wavefront; PCBENV_GEN_LANES (16 / 32) selects the packed builds for
+// experiments where the configuration allows them.
+static inline int gen_group_lanes(int C, int N, int P) {
+    int g = 64;
+    if (const char *ev = getenv("PCBENV_GEN_LANES")) g = atoi(ev);
+    if (g == 16 && C <= 16 && N <= 16 && P <= 64) return 16;
+    if (g == 32 && C <= 32 && N <= 32 && P <= 128) return 32;
+    return 64;
+}
+#define GEN_LDS_BYTES(instStride, G) ((WAVE / (G)) * ((GEN_GROUP_LDS_BYTES(instStride) + 15) & ~15))

@@ -422,10 +422,20 @@ static int check_queue(pcbenv *env) {
 // Fills are started early (half of the queue consumed at worst; fewer, larger refills cost the step kernels less than
 // many small ones) and waited for late, so they overlap the step
 // kernels; the wait is a stream-side event wait, never a host synchronisation.
+// one refill launch: 64 / G environments per wavefront (gen_group_lanes), capped grid
+static void gen_launch_fill(pcbenv *env, hipStream_t s, bool whole_batch) {
+    const int G = gen_group_lanes(env->gp.C, env->cfg.max_num_nets, env->gp.P), epw = WAVE / G;
+    int grid = (env->dp.B + epw - 1) / epw;
+    if (!whole_batch && grid > env->gen_grid) grid = env->gen_grid;
+    const size_t lds = GEN_LDS_BYTES(env->gp.instStride, G);
+    if (G == 16) hipLaunchKernelGGL(k_gen_fill<16>, dim3(grid), dim3(WAVE), lds, s, env->gp);
+    else if (G == 32) hipLaunchKernelGGL(k_gen_fill<32>, dim3(grid), dim3(WAVE), lds, s, env->gp);
+    else hipLaunchKernelGGL(k_gen_fill<64>, dim3(grid), dim3(WAVE), lds, s, env->gp);
+}
 static void gen_start_fill(pcbenv *env, hipStream_t main) {
     hipEventRecord(env->ev_snap, main);
     hipStreamWaitEvent(env->gen_stream, env->ev_snap, 0);
-    hipLaunchKernelGGL(k_gen_fill, dim3(env->dp.B < env->gen_grid ? env->dp.B : env->gen_grid), dim3(WAVE), GEN_LDS_BYTES(env->gp.instStride), env->gen_stream, env->gp);
+    gen_launch_fill(env, env->gen_stream, false);
     hipEventRecord(env->ev_fill, env->gen_stream);
     env->gen_outstanding = true;
     env->since_outstanding = 0;
@@ -484,7 +494,8 @@ extern "C" int pcbenv_instgen_device_enable(pcbenv *env, const uint32_t *seeds_h
     HIP_TRY(env, hipEventCreateWithFlags(&env->ev_fill, hipEventDisableTiming));
     const dim3 grid((d.B + WAVE - 1) / WAVE);
     hipLaunchKernelGGL(k_gen_seed, grid, dim3(WAVE), 0, s, g, seeds_dev);
-    hipLaunchKernelGGL(k_gen_fill, dim3(d.B), dim3(WAVE), GEN_LDS_BYTES(g.instStride), s, g);  // the whole queue, before anything can consume it
+    env->gen_grid = GEN_MAX_GRID;
+    gen_launch_fill(env, s, true);  // the whole queue, before anything can consume it
     HIP_TRY(env, hipGetLastError());
     HIP_TRY(env, hipStreamSynchronize(s));
     hipFree(seeds_dev);

@@ -36,16 +36,20 @@ int main(int argc, char **argv) {
     std::vector<unsigned> hs(B); for (int i = 0; i < B; i++) hs[i] = 7000021u + i;
     CK(hipMemcpy(seeds, hs.data(), 4 * B, hipMemcpyHostToDevice));
     g.queue = queue; g.cursor_pub = cursor;
-    printf("stride %lld istride %lld P %d sizeof(GenState) %zu sizeof(GenLds) %zu\n", stride, istride, g.P, sizeof(GenState), sizeof(GenLds)); fflush(stdout);
+    printf("stride %lld istride %lld P %d sizeof(GenState) %zu\n", stride, istride, g.P, sizeof(GenState)); fflush(stdout);
     hipLaunchKernelGGL(k_gen_seed, dim3((B + 63) / 64), dim3(64), 0, 0, g, seeds);
     CK(hipDeviceSynchronize()); printf("seed ok\n"); fflush(stdout);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0, 0);
-    hipLaunchKernelGGL(k_gen_fill, dim3(B), dim3(64), GEN_LDS_BYTES(g.instStride), 0, g);
+    const int G = argc > 2 ? atoi(argv[2]) : gen_group_lanes(g.C, 8, g.P);
+    const int grid = (B + 64 / G - 1) / (64 / G);
+    if (G == 16) hipLaunchKernelGGL(k_gen_fill<16>, dim3(grid), dim3(64), GEN_LDS_BYTES(g.instStride, 16), 0, g);
+    else if (G == 32) hipLaunchKernelGGL(k_gen_fill<32>, dim3(grid), dim3(64), GEN_LDS_BYTES(g.instStride, 32), 0, g);
+    else hipLaunchKernelGGL(k_gen_fill<64>, dim3(grid), dim3(64), GEN_LDS_BYTES(g.instStride, 64), 0, g);
     hipEventRecord(e1, 0);
     CK(hipGetLastError()); CK(hipDeviceSynchronize());
     float ms = 0; hipEventElapsedTime(&ms, e0, e1);
-    printf("fill ok: %d wavefronts x %d records in %.1f us on an idle GPU = %.1f us per record per wavefront\n", B, Q, ms * 1e3, ms * 1e3 / Q); fflush(stdout);
+    printf("fill ok (G = %d lanes per environment): %d wavefronts, %d records each environment, %.1f us on an idle GPU = %.1f us per record per group\n", G, grid, Q, ms * 1e3, ms * 1e3 / Q); fflush(stdout);
 #ifdef GEN_STAMPS
     {
         std::vector<GenState> st(B);

@@ -70,9 +70,9 @@ typedef volatile LDS3 unsigned long long *LdsU64;
 
 // ---- G lanes per environment ------------------------------------------------------------------------------------
 // A wavefront generates 64 / G records at once: environment `lane / G` of its batch lives in the G lanes of its
-// group, and everything below that says "uniform" means uniform WITHIN A GROUP.  G = 16 is possible when a
-// configuration has at most 16 components, 16 nets and 64 pins (c3, c4), 32 up to 32 / 32 / 128 (c5); the shipped
-// choice is G = 64 for every configuration (gen_group_lanes below: the packed builds measured slower).  Groups diverge freely (different loop counts); every cross-lane operation
+// group, and everything below that says "uniform" means uniform WITHIN A GROUP.  G = 16 when a configuration has at
+// most 16 components, 16 nets and 64 pins (c3, c4: four records per wavefront), 32 up to 32 / 32 / 128 (c5), else 64
+// (gen_group_lanes below).  Groups diverge freely (different loop counts); every cross-lane operation
 // stays inside a group: v_readlane becomes ds_bpermute (per-lane source), the scans stop at the group width, ballots
 // are shifted and masked to the group.
 template <int G> __device__ inline int grl(int v, int idx, int lane) {
@@ -183,6 +183,9 @@ __device__ inline void mt_init_by_array(unsigned *mt, const unsigned *key, int l
 // one element per group lane in registers (free space and id of the component at each sorted position, net
 // probabilities, counts, the pin records) and are read with cross-lane reads / permutes; LDS holds one generator
 // state, the record under construction and the cell list of step 10, per group.
+#ifdef GEN_COUNT_FALLBACK
+__device__ unsigned gen_fallbacks[2];
+#endif
 template <int G> struct NpStream {  // NumPy legacy RandomState pieces
     MtReader<G> rd;
     int lane, has_gauss;
@@ -228,10 +231,15 @@ template <int G> struct NpStream {  // NumPy legacy RandomState pieces
         }
         return X;
     }
-    // RandomState.multinomial(n, p[0..d)), p one element per group lane -> the count of bin `gl`.  The chain of
-    // legacy binomials is sequential, but everything that does not depend on the draws -- the running remainder Sum,
-    // the conditional probabilities p[j] / Sum, which tail the inversion works on and its log(q) -- is evaluated for
-    // all bins at once first (the same operations on the same operands as numpy's loop).
+    // RandomState.multinomial(n, p[0..d)), p one element per group lane -> the count of bin `gl`.  NumPy runs a chain
+    // of legacy binomials, bin j on whatever is left of n.  Everything that does not depend on the draws -- the
+    // running remainder Sum, the conditional probabilities p[j] / Sum, which tail the inversion works on and its
+    // log(q) -- is evaluated for all bins at once first (the same operations on the same operands as numpy's loop).
+    // Then the fast path: a bin's binomial consumes exactly one uniform variate (two words of the stream) unless it is
+    // redrawn (X > bound, never seen), so bin j's variate is known in advance, and lane j tabulates its inversion for
+    // EVERY possible remainder 1..n (n <= 15: four bits each); the chain itself is then a table walk.  Whenever an
+    // assumption of the fast path does not hold (block refill inside the chain, a redraw, n > 15, a bin beyond the
+    // inversion algorithm's range) the chain runs one binomial after the other as numpy does.
     __device__ int multinomial(int n, double p_l, int d, bool *ok) {
         const int gl = lane & (G - 1);
         double Sum = 1.0, sum_l = 1.0;
@@ -239,20 +247,74 @@ template <int G> struct NpStream {  // NumPy legacy RandomState pieces
         const double P_l = p_l / sum_l;                      // random_binomial(p = P_l, n = what is left)
         const bool upper_l = !(P_l <= 0.5);                  // p > 0.5: draw the complement with q = 1 - p
         const double pp_l = upper_l ? 1.0 - P_l : P_l, qq_l = 1.0 - pp_l, lg_l = log(qq_l);
-        int cnt_l = 0;
-        int dn = n;
-        for (int j = 0; j < d - 1; j++) {
-            const double P = grl<G>(P_l, j, lane);
-            int x = 0;
-            if (dn != 0 && P != 0.0) {
-                const double pp = grl<G>(pp_l, j, lane);
-                if (!(pp * (double)dn <= 30.0)) { *ok = false; return cnt_l; }  // BTPE would be needed: outside the sizes this library supports
-                x = binomial_inversion(dn, pp, grl<G>(qq_l, j, lane), grl<G>(lg_l, j, lane));
-                if (grl<G>((int)upper_l, j, lane)) x = dn - x;
+        const bool bin_l = gl < d - 1, draws_l = bin_l && P_l != 0.0;   // random_binomial returns 0 without a draw for p == 0
+        if (rd.pos >= 624) { mt_regenerate<G>(rd.mt, gl); rd.pos = 0; rd.base = -1; }
+        const int incl = gscan<G>(draws_l ? 1 : 0, lane);
+        const int ndraw = grl<G>(incl, G - 1, lane);
+        bool fast = n <= 15 && rd.pos + 2 * ndraw <= 624;
+#ifdef GEN_COUNT_FALLBACK
+        if (lane == 0) atomicAdd(gen_fallbacks + 1, 1u);
+#endif
+        u64 tab_l = 0ull;
+        if (fast) {
+            bool bad_l = false;
+            if (draws_l) {
+                const int w0 = rd.pos + 2 * (incl - 1);
+                unsigned a = rd.mt[w0], b = rd.mt[w0 + 1];
+                a ^= (a >> 11); a ^= (a << 7) & 0x9d2c5680u; a ^= (a << 15) & 0xefc60000u; a ^= (a >> 18);
+                b ^= (b >> 11); b ^= (b << 7) & 0x9d2c5680u; b ^= (b << 15) & 0xefc60000u; b ^= (b >> 18);
+                const double U0 = ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0;
+                for (int m = 1; m <= n; m++) {  // legacy_random_binomial_inversion(m, pp) on this bin's variate
+                    if (!(pp_l * (double)m <= 30.0)) { bad_l = true; break; }
+                    const double qn = exp((double)m * lg_l), np = (double)m * pp_l;
+                    const double bb = np + 10.0 * sqrt(np * qq_l + 1);
+                    const int bound = (int)((double)m < bb ? (double)m : bb);
+                    int X = 0;
+                    double px = qn, U = U0;
+                    while (U > px) {
+                        X++;
+                        if (X > bound) { bad_l = true; break; }
+                        U -= px; px = ((double)(m - X + 1) * pp_l * px) / ((double)X * qq_l);
+                    }
+                    if (bad_l) break;
+                    tab_l |= (u64)(unsigned)(upper_l ? m - X : X) << (4 * m);
+                }
             }
-            if (gl == j) cnt_l = x;
-            dn -= x;
-            if (dn <= 0) break;
+            if (gballot<G>(bad_l, lane)) fast = false;
+        }
+        int cnt_l = 0, dn = n;
+        if (fast) {
+            const u64 draws = gballot<G>(draws_l, lane);
+            int used = 0;
+            for (int j = 0; j < d - 1; j++) {
+                int x = 0;
+                if (dn != 0 && ((draws >> j) & 1ull)) {
+                    const unsigned lo32 = (unsigned)grl<G>((int)(unsigned)tab_l, j, lane), hi32 = (unsigned)grl<G>((int)(unsigned)(tab_l >> 32), j, lane);
+                    x = (int)(((((u64)hi32 << 32) | lo32) >> (4 * dn)) & 15ull);
+                    used += 2;
+                }
+                if (gl == j) cnt_l = x;
+                dn -= x;
+                if (dn <= 0) break;
+            }
+            rd.pos += used;
+        } else {
+#ifdef GEN_COUNT_FALLBACK
+            atomicAdd(gen_fallbacks, 1u);
+#endif
+            for (int j = 0; j < d - 1; j++) {
+                const double P = grl<G>(P_l, j, lane);
+                int x = 0;
+                if (dn != 0 && P != 0.0) {
+                    const double pp = grl<G>(pp_l, j, lane);
+                    if (!(pp * (double)dn <= 30.0)) { *ok = false; return cnt_l; }  // BTPE would be needed: outside the sizes this library supports
+                    x = binomial_inversion(dn, pp, grl<G>(qq_l, j, lane), grl<G>(lg_l, j, lane));
+                    if (grl<G>((int)upper_l, j, lane)) x = dn - x;
+                }
+                if (gl == j) cnt_l = x;
+                dn -= x;
+                if (dn <= 0) break;
+            }
         }
         if (dn > 0 && gl == d - 1) cnt_l = dn;
         return cnt_l;
@@ -490,16 +552,13 @@ __global__ __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(WAVE) vo
     }
 }
 // lanes per environment for a configuration (see above); LDS bytes of a refill launch
-// Measured (tools/gen_harness.hip, idle MI355X, c3 / c4 records): G = 64: 101-103 us per record per wavefront; G = 32: ~1 000 us
-// and G = 16: ~500 us per record per group, i.e. 121-250 us per record per wavefront -- the cross-lane reads that are a
-// v_readlane at G = 64 become ds_bpermute round trips inside the dependent chain, which costs more than packing gains.
-// So every configuration runs one environment per wavefront; PCBENV_GEN_LANES (16 / 32) selects the packed builds for
-// experiments where the configuration allows them.
+// Measured on c3 (bench.py fresh-instance leg, 4 096 environments, same box): G = 64: 126 M env-steps/s, G = 32: 145 M,
+// G = 16: 156 M (replayed queue: 200 M).  Packing pays although a cross-lane read is a ds_bpermute round trip at G < 64
+// instead of a v_readlane: with the multinomial chains tabulated, the dependent chain of a record is short enough.
+// PCBENV_GEN_LANES = 16 / 32 / 64 forces a wider group (experiments, tests).
 static inline int gen_group_lanes(int C, int N, int P) {
-    int g = 64;
-    if (const char *ev = getenv("PCBENV_GEN_LANES")) g = atoi(ev);
-    if (g == 16 && C <= 16 && N <= 16 && P <= 64) return 16;
-    if (g == 32 && C <= 32 && N <= 32 && P <= 128) return 32;
-    return 64;
+    int g = (C <= 16 && N <= 16 && P <= 64) ? 16 : (C <= 32 && N <= 32 && P <= 128) ? 32 : 64;
+    if (const char *ev = getenv("PCBENV_GEN_LANES")) { const int f = atoi(ev); if ((f == 32 || f == 64) && f > g) g = f; }
+    return g;
 }
 #define GEN_LDS_BYTES(instStride, G) ((WAVE / (G)) * ((GEN_GROUP_LDS_BYTES(instStride) + 15) & ~15))

@@ -525,13 +525,16 @@ GEN_CASES = {
 }
 
 
-@pytest.mark.parametrize("name,B", [("c2", 2048), ("c3", 4096), ("c4", 1024), ("c5", 512), ("small_spatial", 4096),
-                                    ("small_pin", 4096), ("mid_spatial", 2048), ("rect_6x6", 1024)])
-def test_device_instance_generator_equals_the_host_streams(name, B):
+@pytest.mark.parametrize("name,B,lanes", [("c2", 2048, 0), ("c3", 4096, 0), ("c4", 1024, 0), ("c5", 512, 0), ("small_spatial", 4096, 0),
+                                          ("small_pin", 4096, 0), ("mid_spatial", 2048, 0), ("rect_6x6", 1024, 0),
+                                          ("c3", 1024, 32), ("c3", 1024, 64), ("c5", 256, 64), ("small_spatial", 1024, 64)])
+def test_device_instance_generator_equals_the_host_streams(name, B, lanes, monkeypatch):
     """k_gen_fill against csrc/instance_gen.cpp (itself pinned to the reference's generate_instances by
     test_instance_gen_native.py and the golden tables): the whole queue after enabling, and -- after rollouts that
     consume and refill it several times over -- every record an environment is about to take."""
     from pcbenv.instances import NativeInstanceStreams
+    if lanes:  # lanes per environment of the generator kernel (default: the narrowest group the configuration allows)
+        monkeypatch.setenv("PCBENV_GEN_LANES", str(lanes))
     cfg = GEN_CASES[name]()
     Q = 8
     env = BatchedPlacementEnv(cfg, B, queue_depth=Q, run_seed=7, auto_reset=True)

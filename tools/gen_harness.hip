@@ -50,6 +50,9 @@ int main(int argc, char **argv) {
     CK(hipGetLastError()); CK(hipDeviceSynchronize());
     float ms = 0; hipEventElapsedTime(&ms, e0, e1);
     printf("fill ok (G = %d lanes per environment): %d wavefronts, %d records each environment, %.1f us on an idle GPU = %.1f us per record per group\n", G, grid, Q, ms * 1e3, ms * 1e3 / Q); fflush(stdout);
+#ifdef GEN_COUNT_FALLBACK
+    { unsigned fb[2]; CK(hipMemcpyFromSymbol(fb, HIP_SYMBOL(gen_fallbacks), 8)); printf("multinomial calls %u, lane-level fallback entries %u (= %u wavefront fallbacks at 64 lanes)\n", fb[1], fb[0], fb[0] / 64); }
+#endif
 #ifdef GEN_STAMPS
     {
         std::vector<GenState> st(B);

@@ -182,7 +182,7 @@ __device__ inline void mt_init_by_array(unsigned *mt, const unsigned *key, int l
 // All of the below runs uniformly within a group: every lane of the group holds the same scalars.  Small tables live
 // one element per group lane in registers (free space and id of the component at each sorted position, net
 // probabilities, counts, the pin records) and are read with cross-lane reads / permutes; LDS holds one generator
-// state, the record under construction and the cell list of step 10, per group.
+// state and the record under construction, per group.
 #ifdef GEN_COUNT_FALLBACK
 __device__ unsigned gen_fallbacks[2];
 #endif
@@ -341,9 +341,9 @@ template <int G> __device__ inline double np_sum_lanes(double a_l, int n, int la
     return res;
 }
 
-// The group's LDS: one generator state, the record, the cell list of step 10.
-struct GrpLds { LdsU32 mt; LdsU64 rec; volatile LDS3 unsigned char *cells; };
-#define GEN_GROUP_LDS_BYTES(instStride) (624 * 4 + (int)(instStride) + PCBENV_MAX_PINS_PER_COMPONENT)
+// The group's LDS: one generator state and the record.
+struct GrpLds { LdsU32 mt; LdsU64 rec; };
+#define GEN_GROUP_LDS_BYTES(instStride) (624 * 4 + (int)(instStride))
 
 // One record of the group's stream into L.rec (wire format of include/pcbenv.h).  Uniform within the group.
 template <int G> __device__ inline int gen_record(const GenParams &c, const GrpLds &L, GenState *g, NpStream<G> &rs, int &py_pos_, int lane) {
@@ -463,25 +463,28 @@ template <int G> __device__ inline int gen_record(const GenParams &c, const GrpL
         const int hw = grl<G>(hw_l, cid, lane), w = hw >> 8;
         int ncell = (hw & 0xFF) * w;
         const unsigned wmagic = (65536u + (unsigned)w - 1u) / (unsigned)w;  // cell / w == (cell * wmagic) >> 16 for cell < 4160, w <= 16
-        for (int i = gl; i < ncell; i += G) L.cells[i] = (unsigned char)i;
+        // `cells` = the component's cells in row-major order with the used ones removed: a bit set.  cells[r] is the
+        // r-th set bit, list.remove() clears it (the list stays sorted, so order is preserved as in the reference).
+        u64 cells = ncell >= 64 ? ~0ull : ((1ull << ncell) - 1ull);
         #pragma unroll
         for (int ch = 0; ch < 4; ch++) {
             u64 mine = gballot<G>((int)((rec_r[ch] >> 24) & 0xFF) == cid && rec_r[ch] != ~0ull, lane);
             while (mine) {
                 const int jl = __ffsll((long long)mine) - 1;
                 mine &= mine - 1;
-                int kbits = 0;
-                for (int v = ncell; v; v >>= 1) kbits++;
+                const int kbits = 32 - __clz(ncell);
                 unsigned r;
                 do { r = py.next(lane) >> (32 - kbits); } while ((int)r >= ncell);  // _randbelow_with_getrandbits
-                const int cell = L.cells[r];
-                for (int t0 = (int)r; t0 + 1 < ncell; t0 += G) {  // list.remove(value): cells are unique; G cells per step, ascending
-                    const int t = t0 + gl;
-                    const unsigned char nxt = t + 1 < ncell ? L.cells[t + 1] : (unsigned char)0;
-                    __builtin_amdgcn_wave_barrier();
-                    if (t + 1 < ncell) L.cells[t] = nxt;
-                    __builtin_amdgcn_wave_barrier();
+                int cell = 0, k = (int)r;
+                {   // position of the k-th set bit: binary search on popcounts
+                    u64 wbits = cells;
+                    #pragma unroll
+                    for (int width = 32; width >= 1; width >>= 1) {
+                        const int cpop = __popcll(wbits & ((1ull << width) - 1ull));
+                        if (k >= cpop) { k -= cpop; wbits >>= width; cell += width; }
+                    }
                 }
+                cells &= ~(1ull << cell);
                 ncell--;
                 const unsigned cx = ((unsigned)cell * wmagic) >> 16, cy = (unsigned)cell - cx * (unsigned)w;
                 if (gl == jl) rec_r[ch] |= (unsigned long long)cx | ((unsigned long long)cy << 8);
@@ -526,7 +529,6 @@ __global__ __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(WAVE) vo
     GrpLds L;
     L.mt = (LdsU32)(gen_smem + grp * per_group);
     L.rec = (LdsU64)(gen_smem + grp * per_group + 624 * 4);
-    L.cells = (volatile LDS3 unsigned char *)(gen_smem + grp * per_group + 624 * 4 + c.instStride);
     for (int e0 = blockIdx.x * EPW; e0 < c.B; e0 += gridDim.x * EPW) {
         const int e = e0 + grp;
         if (e >= c.B) continue;

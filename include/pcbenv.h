@@ -158,7 +158,9 @@ int pcbenv_bind_buffers(pcbenv *env, const pcbenv_buffers *buffers);
  * (selected + t) % num_slots.  This is how a rollout loop (RLlib's sampler, the simulate() loops under agent/random) keeps
  * the observation of every step -- obs[t] -- without copying tensors after each call.  With num_slots > 1 a step
  * cannot rely on what an earlier step left in its destination, so every bound tensor is written whole (the float64
- * feature tensors and component_grid included); PCBENV_FLAG_INCREMENTAL_OBS requires num_slots == 1.
+ * feature tensors and component_grid included); PCBENV_FLAG_INCREMENTAL_OBS requires num_slots == 1.  A masked
+ * pcbenv_reset writes only the masked environments' rows of the selected slot (the explicit loop "step, then
+ * reset the finished ones" therefore keeps one slot per step).
  * pcbenv_bind_buffers(env, b) == pcbenv_bind_buffers_slots(env, b, 1). */
 int pcbenv_bind_buffers_slots(pcbenv *env, const pcbenv_buffers *buffers, int32_t num_slots);
 int pcbenv_select_slot(pcbenv *env, int32_t slot);

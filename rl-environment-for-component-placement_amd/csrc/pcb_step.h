@@ -147,6 +147,8 @@ __global__ __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(64 * NW)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (!TRAJ) p.stream_stores = STREAM;  // the launch's choice as a compile-time constant: only one store policy is compiled in
     const int num_steps = TRAJ ? num_steps_ : 1;
+    // above the generator's wavefronts (priority 0) when both share a SIMD: the step kernel is the latency-critical one
+    __builtin_amdgcn_s_setprio(3);
     const int e = blockIdx.x, lane = threadIdx.x;
     const int H = p.H, W = p.W, HW = H * W;
     STAMP_RT(30);

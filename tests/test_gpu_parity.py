@@ -465,7 +465,9 @@ def test_trajectory_slots_every_tensor(name, mode):
 
 
 @pytest.mark.parametrize("name,B,T,S", [("c3", 512, 40, 41), ("c4", 256, 36, 37), ("c2", 512, 20, 7), ("c5", 64, 40, 41),
-                                        ("small_spatial", 256, 30, 31), ("c1", 64, 12, 13)])
+                                        ("small_spatial", 256, 30, 31), ("c1", 64, 12, 13),
+                                        # BASELINE batches, one episode + the reset behind it, every tensor of every slot
+                                        ("c3", 4096, 17, 18), ("c4", 4096, 17, 18), ("c2", 1024, 17, 18), ("c5", 512, 33, 34)])
 def test_persistent_rollout_fills_the_trajectory(name, B, T, S):
     """pcbenv_rollout_sampled = ONE launch for T steps with the state held in LDS: slot (1 + t) % S of every tensor, the
     recorded actions, rewards, dones and infos against the oracle stepping the same actions.  (S < T: the slots wrap.)"""
@@ -482,7 +484,11 @@ def test_persistent_rollout_fills_the_trajectory(name, B, T, S):
             for i in np.flatnonzero(mask):
                 ob.env(i).reset()
             return
-        ob.reset_packed(np.stack([packed[cursor[i] % Q][i] for i in range(B)]), mask.astype(np.uint8), 8)
+        sel = cursor % Q
+        rec = packed[0].copy()
+        for q_ in range(1, Q):
+            rec[sel == q_] = packed[q_][sel == q_]
+        ob.reset_packed(rec, mask.astype(np.uint8), 16)
         cursor[mask.astype(bool)] += 1
 
     env.reset()                       # slot 0
@@ -499,7 +505,7 @@ def test_persistent_rollout_fills_the_trajectory(name, B, T, S):
     for t in range(T):
         a1 = single.rollout_step(t)[4].cpu().numpy()
         assert np.array_equal(a1, acts[t]), t
-        rr, dd, ii = ob.step(acts[t], 8)
+        rr, dd, ii = ob.step(acts[t], 16)
         oracle_reset(dd)
         if t + S < T:
             continue                  # this slot has been overwritten by a later step
@@ -510,7 +516,7 @@ def test_persistent_rollout_fills_the_trajectory(name, B, T, S):
             has = dd.astype(bool)
             assert _same_bits(info[s_][has], ii[has]) and np.isnan(info[s_][~has]).all(), t
         for k in traj:
-            assert ob.first_mismatch(k, traj[k][s_], 8) < 0, (t, k)
+            assert ob.first_mismatch(k, traj[k][s_], 16) < 0, (t, k)
     env.close(); single.close()
 
 

@@ -455,6 +455,7 @@ def main():
                 "roofline": roof, "cpu_baseline": cpu, "fresh_instances": fresh, "rollout": rollout}
         print(json.dumps(line), flush=True)
     if dist:
+        dist.barrier()  # rank 0 has printed: leave together
         dist.destroy_process_group()
 
 

@@ -31,7 +31,7 @@ struct BsEntry {
     }
 };
 static_assert(sizeof(BsEntry) == 32 && sizeof(CSet) == 48, "beam LDS records");
-#define BEAM_LDS_PER_NET(k) (64 * (k) * (k) + 16 * 8 + 16 + 2 * 48)
+#define BEAM_LDS_PER_NET(k) (64 * (k) * (k) + 16 * 8 + 16 + 2 * 48 + 16 * 4)
 #define BEAM_LDS_BYTES(nets, k) ((nets) * BEAM_LDS_PER_NET(k))
 
 // points to visit of one net: the net's pins without the start pin `st`
@@ -144,6 +144,7 @@ __device__ inline int cs_difference_order(CSet *A, CSet *R, int m, unsigned visi
     return n;
 }
 
+#ifdef PCBENV_BEAM_SERIAL
 // One net, one lane: fills the net's slots [s, s+cnt) of the segment view with the beam route.
 // `scratch` = this net's BEAM_LDS_PER_NET(k) bytes of LDS.
 __device__ inline void beam_route_net(const SegView &v, const PinRec *pins, int s, int cnt, int k, unsigned char *scratch) {
@@ -251,15 +252,375 @@ __device__ inline void beam_route_net(const SegView &v, const PinRec *pins, int 
     }
 }
 
+#endif
+
+// ---- boundary ties, fast path ------------------------------------------------------------------------------
+// `A = set(points)` and the tuple hashes depend on the net only: built once per net (first tie) and kept in LDS.
+// (Low 32 bits of each hash: they carry the first five perturb steps of an 8-slot walk; a longer walk -- occupied slots
+// can be revisited -- recomputes the full hash.)
+__device__ inline void cs_build_points(CSet *A, CSet *tmp, unsigned *hs, int m, const NetPts &pt) {
+    cs_init(A, 8);
+    for (int i = 0; i < m; i++) { hs[i] = (unsigned)tuple_hash2(pt.x(i), pt.y(i)); cs_add(A, tmp, i, pt); }
+}
+// Iteration order of `A - visited` when the result has at most 4 elements and comes from the "fresh set filled in
+// A's slot order" branch of set_difference: the result table keeps its 8 slots (no resize before the 5th insert), so
+// it lives in one 64-bit register, one byte per slot (mask 7: LINEAR_PROBES never applies, only the perturb walk).
+// Returns the number of elements, their point indices in iteration order packed one per byte.
+__device__ inline int cs_small_difference_order(const CSet *A, const unsigned *hs, unsigned visited, const NetPts &pt, unsigned *packed) {
+    const unsigned *tw = (const unsigned *)A->t;  // 4-byte aligned (offset 12 of a 16-byte aligned record)
+    const int nw = (A->mask + 1) >> 2;            // 2 or 8 words
+    unsigned w[8];
+    #pragma unroll
+    for (int i = 0; i < 8; i++) w[i] = i < nw ? tw[i < nw ? i : 0] : 0xFFFFFFFFu;
+    u64 rt = ~0ull;
+    int ns = 0;
+    #pragma unroll
+    for (int i = 0; i < 8; i++) {
+        if (w[i] == 0xFFFFFFFFu) continue;  // four empty slots
+        #pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const unsigned c = (w[i] >> (8 * b)) & 0xFFu;
+            if (c >= CS_DUMMY || (visited >> c & 1u)) continue;
+            u64 perturb = hs[c];
+            unsigned slot = (unsigned)perturb & 7u;
+            for (int step = 1; ((rt >> (8 * slot)) & 0xFFull) != 0xFFull; step++) {
+                if (step == 6) perturb = tuple_hash2(pt.x(c), pt.y(c)) >> 25;  // the cached low word has run out: the full hash, five steps in
+                perturb >>= 5;
+                slot = (unsigned)(((u64)slot * 5u + 1u + perturb) & 7u);
+            }
+            rt = (rt & ~(0xFFull << (8 * slot))) | ((u64)c << (8 * slot));
+            ns++;
+        }
+    }
+    unsigned out = 0; int n = 0;
+    #pragma unroll
+    for (int sl = 0; sl < 8; sl++) {
+        const unsigned c = (unsigned)(rt >> (8 * sl)) & 0xFFu;
+        if (c != 0xFFu) { out |= c << (8 * n); n++; }
+    }
+    *packed = out;
+    return ns;
+}
+
+// ---- beam search laid out for latency -----------------------------------------------------------------------
+// A terminal wavefront is alone with a short dependent chain (one level per pin of the net): what counts is the
+// number of dependent instructions and LDS round trips per level, not lanes.  So:
+//  * a net gets PCBENV_MAX_BEAM_WIDTH lanes, one per heappop of a level: all entries of a level have the same length,
+//    hence the same number of unvisited points and the same number of children -- lane t selects the t-th smallest
+//    queue entry by itself, expands it and writes its children to next[t * take ...): the only thing lanes of a net
+//    share is the queue in LDS (wave-level ordering, a net's lanes never span two wavefronts);
+//  * "the k nearest unvisited points, index order among equals" is taken on integer keys (dx*dx + dy*dy) << 4 | index
+//    held in registers: coordinates are small integers, the squared distance is exact and np.linalg.norm is strictly
+//    monotone on it, so the order (and the boundary tie) is the reference's; only the priorities need float64 norms;
+//  * the farthest-from-centroid start pin and the route segments are computed one pin per lane before / after;
+//  * the rare boundary tie still runs the serial CPython-set model, the lanes of a net taking turns (shared scratch).
+// Same results as the one-lane-per-net search (kept under -DPCBENV_BEAM_SERIAL for A/B runs): same pop order (first
+// index among fully equal entries), same children in the same queue order.
+#define BEAM_LANES_PER_NET PCBENV_MAX_BEAM_WIDTH
+#if defined(PCBENV_STAMPS) && defined(PCBENV_STAMPS_BEAM)  // phase cycles of the search, accumulated by lane 0 into stamp slots 26..29
+#define BEAM_T0() unsigned long long bt0_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(bt0_) :: "memory")
+#define BEAM_ACC(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); if (threadIdx.x == 0 && beam_dbg) beam_dbg[(size_t)blockIdx.x * 32 + (k)] += t_ - bt0_; bt0_ = t_; } while (0)
+#else
+#define BEAM_T0() do { } while (0)
+#define BEAM_ACC(k) do { } while (0)
+#endif
+__device__ inline void wave_lds_order() {  // LDS traffic of one wavefront executes in order: only the compiler must not reorder
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+}
+// all pins of a net, original order (index = offset from the net's first slot), one byte per coordinate
+template <int MAXC> struct NetAll {
+    u64 xs0, xs1, ys0, ys1;
+    __device__ int x(int i) const { return (int)(((MAXC <= 8 || i < 8 ? xs0 : xs1) >> ((i & 7) * 8)) & 0xFFull); }
+    __device__ int y(int i) const { return (int)(((MAXC <= 8 || i < 8 ? ys0 : ys1) >> ((i & 7) * 8)) & 0xFFull); }
+    __device__ static NetAll load(const PinRec *p, int cnt) {
+        NetAll n{0ull, 0ull, 0ull, 0ull};
+        #pragma unroll
+        for (int i = 0; i < MAXC; i++) {  // all loads go out together; slots past the net repeat pin 0 and are masked
+            const PinRec pr = p[i < cnt ? i : 0];
+            const u64 x = i < cnt ? (u64)(unsigned char)pr.abs_x << ((i & 7) * 8) : 0ull, y = i < cnt ? (u64)(unsigned char)pr.abs_y << ((i & 7) * 8) : 0ull;
+            if (i < 8) { n.xs0 |= x; n.ys0 |= y; } else { n.xs1 |= x; n.ys1 |= y; }
+        }
+        return n;
+    }
+};
+// python's list comparison of two queued paths of equal priority (entries hold pin indices; all paths of a queue have one length)
+template <int MAXC> __device__ inline bool path_less(const BsEntry &a, const BsEntry &e, const NetAll<MAXC> &pt) {
+    bool less = a.len() < e.len();
+    const int n = a.len() < e.len() ? a.len() : e.len();
+    for (int j = 0; j < n; j++) {
+        const int pa = a.at(j), pb = e.at(j);
+        const int ax = pt.x(pa), ay = pt.y(pa), bx = pt.x(pb), by = pt.y(pb);
+        if (ax != bx) { less = ax < bx; break; }
+        if (ay != by) { less = ay < by; break; }
+    }
+    return less;
+}
+// SMALL: nets of <= 8 pins and beam widths <= 2 (queue <= 4 entries): everything unrolled in registers
+template <bool SMALL>
+__device__ __forceinline__ void beam_route_lanes(const SegView &v, const PinRec *pins, int s, int cnt, int st, int k, unsigned char *scratch, int t, unsigned long long *beam_dbg) {
+    constexpr int MAXC = SMALL ? 8 : PCBENV_MAX_PINS_PER_NET, MAXQ = SMALL ? 4 : PCBENV_MAX_BEAM_WIDTH * PCBENV_MAX_BEAM_WIDTH;
+    constexpr unsigned KINF = 0x7FFFFFFFu;
+    BEAM_T0();
+    BsEntry *queue = (BsEntry *)scratch, *next = queue + k * k;
+    double *dist = (double *)(scratch + 64 * k * k);
+    unsigned char *order = (unsigned char *)(dist + 16);
+    CSet *A = (CSet *)(order + 16), *R = A + 1;
+    unsigned *hs = (unsigned *)(R + 1);  // tuple hashes (low words) of the points to visit, valid once A is built
+    const NetAll<MAXC> pt = NetAll<MAXC>::load(pins + s, cnt);
+    const unsigned all = (1u << cnt) - 1u;
+    int qn = 1;
+    if (t == 0) {
+        BsEntry e0; e0.prio = 0.0; e0.meta = (1ull << 16) | (1ull << st); e0.p0 = (u64)(unsigned)st; e0.p1 = 0ull; queue[0] = e0;
+        A->mask = 0;  // "the points' set is not built yet" (a built table has mask >= 7)
+    }
+    wave_lds_order();
+    BEAM_ACC(26);
+    for (;;) {
+        const int pops = k < qn ? k : qn;
+        const bool worker = t < pops;
+        // heappop number t: the (t+1)-th smallest (priority, path) of the queue, first index among fully equal entries
+        int sel = 0;
+        if (SMALL) {
+            double pr[MAXQ];
+            #pragma unroll
+            for (int i = 0; i < MAXQ; i++) { const double q = queue[i].prio; pr[i] = i < qn ? q : __builtin_inf(); }  // stale slots: read, ranked last
+            // rank of every entry by priority alone (six compares); two live entries of equal priority are rare and
+            // take the general selection below, where python's path comparison breaks the tie
+            int rk[MAXQ]; bool eq = false;
+            #pragma unroll
+            for (int i = 0; i < MAXQ; i++) rk[i] = 0;
+            #pragma unroll
+            for (int i = 0; i < MAXQ; i++) {
+                #pragma unroll
+                for (int j = i + 1; j < MAXQ; j++) {
+                    const bool lt = pr[j] < pr[i];
+                    rk[i] += lt ? 1 : 0; rk[j] += lt ? 0 : 1;
+                    eq |= j < qn && pr[j] == pr[i];
+                }
+            }
+            if (!eq) {
+                const int want = t < pops ? t : pops - 1;
+                #pragma unroll
+                for (int i = 0; i < MAXQ; i++) if (rk[i] == want) sel = i;
+            } else {
+                unsigned taken = 0;
+                for (int it = 0; it <= t && it < pops; it++) {
+                    int best = -1; double bp = 0.0;
+                    #pragma unroll
+                    for (int i = 0; i < MAXQ; i++) {
+                        if (i >= qn || (taken >> i & 1u)) continue;
+                        bool less = best < 0 || pr[i] < bp;
+                        if (best >= 0 && pr[i] == bp) less = path_less<MAXC>(queue[i], queue[best], pt);
+                        if (less) { best = i; bp = pr[i]; }
+                    }
+                    taken |= 1u << best; sel = best;
+                }
+            }
+        } else {
+            unsigned taken = 0;
+            for (int it = 0; it <= t && it < pops; it++) {
+                int best = -1; double bp = 0.0;
+                for (int i = 0; i < qn; i++) {
+                    if (taken >> i & 1u) continue;
+                    const double pi = queue[i].prio;
+                    bool less = best < 0 || pi < bp;
+                    if (best >= 0 && pi == bp) less = path_less<MAXC>(queue[i], queue[best], pt);
+                    if (less) { best = i; bp = pi; }
+                }
+                taken |= 1u << best; sel = best;
+            }
+        }
+        BEAM_ACC(27);
+        const BsEntry e = queue[sel];
+        const unsigned vis = e.visited();
+        if (vis == all) {  // every entry of this level is a complete path: the first pop is the answer
+            wave_lds_order();
+            if (t == 0) *(BsEntry *)scratch = e;
+            break;
+        }
+        const int cur = e.at(e.len() - 1);
+        const int ux = pt.x(cur), uy = pt.y(cur);
+        const int cntn = __popc(all & ~vis), take = cntn < k ? cntn : k;
+        unsigned chosen[PCBENV_MAX_BEAM_WIDTH + 1];  // the k + 1 smallest keys, ascending
+        if (SMALL) {
+            unsigned key[MAXC];
+            #pragma unroll
+            for (int j = 0; j < MAXC; j++) {
+                const int dx = ux - pt.x(j), dy = uy - pt.y(j);
+                key[j] = (j < cnt && !(vis >> j & 1u)) ? (((unsigned)(dx * dx + dy * dy) << 4) | (unsigned)j) : KINF;
+            }
+            #pragma unroll
+            for (int r = 0; r <= PCBENV_MAX_BEAM_WIDTH; r++) {
+                if (r > 2) { chosen[r] = KINF; continue; }
+                unsigned mn = KINF;
+                #pragma unroll
+                for (int j = 0; j < MAXC; j++) mn = min(mn, key[j]);
+                chosen[r] = mn;
+                #pragma unroll
+                for (int j = 0; j < MAXC; j++) key[j] = key[j] == mn ? KINF : key[j];
+            }
+        } else {  // wide nets / beams: the keys are recomputed per round instead of held (register pressure, not speed)
+            unsigned prev = 0u;
+            #pragma unroll
+            for (int r = 0; r <= PCBENV_MAX_BEAM_WIDTH; r++) {
+                unsigned mn = KINF;
+                if (r <= k) {
+                    for (int j = 0; j < cnt; j++) {
+                        const int dx = ux - pt.x(j), dy = uy - pt.y(j);
+                        const unsigned kj = (((unsigned)(dx * dx + dy * dy) << 4) | (unsigned)j) + 1u;  // + 1: above `prev` = 0 in round 0
+                        if (!(vis >> j & 1u) && kj > prev) mn = min(mn, kj);
+                    }
+                }
+                prev = mn;
+                chosen[r] = mn == KINF ? KINF : mn - 1u;
+            }
+        }
+        bool tie = false;
+        #pragma unroll
+        for (int q = 1; q <= PCBENV_MAX_BEAM_WIDTH; q++) if (q == k && cntn > k) tie = (chosen[q - 1] >> 4) == (chosen[q] >> 4);
+#ifdef PCBENV_BEAM_NOTIE  // diagnostic only (wrong on boundary ties): what the search costs without the set model
+        tie = false;
+#endif
+        BsEntry *dst = next + t * take;
+        if (worker && !tie) {
+            #pragma unroll
+            for (int r = 0; r < PCBENV_MAX_BEAM_WIDTH; r++) {
+                if (r >= take || (SMALL && r >= 2)) continue;
+                const int j = (int)(chosen[r] & 15u);
+                BsEntry w = e; w.push(j); w.prio = e.prio + norm2((double)(ux - pt.x(j)), (double)(uy - pt.y(j)));
+                dst[r] = w;
+            }
+        }
+        BEAM_ACC(28);
+        // boundary tie: the CPython set order decides who is kept.  The model works on the points to visit (the
+        // pins without the start pin, list order); the lanes of a net share its scratch and take turns.
+        const bool my_tie = worker && tie;
+        if (__ballot(my_tie) != 0ull)  // (of the lanes still searching)
+        for (int turn = 0; turn < BEAM_LANES_PER_NET; turn++) {
+            if (!(my_tie && t == turn)) continue;
+            const int m = cnt - 1;
+            const NetPts pv = NetPts::load(pins + s, cnt, st);
+            const unsigned vpt = (vis & ((1u << st) - 1u)) | ((vis >> (st + 1)) << st);  // visited without the start pin's bit
+            if (A->mask == 0) cs_build_points(A, R, hs, m, pv);  // first tie of this net
+            int nset; unsigned packed = 0;
+            const int nleft = m - (int)__popc(vpt);
+            const bool small = !((m >> 2) > (int)__popc(vpt)) && nleft <= 4;
+            if (small) nset = cs_small_difference_order(A, hs, vpt, pv, &packed);
+            else {  // the general model works on a copy of the points' table (it recycles its first argument)
+                CSet *A2 = (CSet *)dist;
+                nset = cs_difference_order(A2, R, m, vpt, pv, order);
+            }
+            // sorted(key=distance) is stable: ties keep the iteration order; exact integer keys as above
+            unsigned skey[4];
+            if (small) {
+                #pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int o = (int)((packed >> (8 * i)) & 0xFFu);
+                    const int dx = ux - pv.x(o), dy = uy - pv.y(o);
+                    skey[i] = i < nset ? (((unsigned)(dx * dx + dy * dy) << 8) | ((unsigned)i << 4) | (unsigned)o) : KINF;
+                }
+                #pragma unroll
+                for (int r = 0; r < 4; r++) {  // `take` smallest (distance, position in the iteration order)
+                    unsigned mn = KINF;
+                    #pragma unroll
+                    for (int i = 0; i < 4; i++) mn = min(mn, skey[i]);
+                    #pragma unroll
+                    for (int i = 0; i < 4; i++) skey[i] = skey[i] == mn ? KINF : skey[i];
+                    if (r < take) {
+                        const int o = (int)(mn & 15u);
+                        BsEntry q = e; q.push(o + (o >= st ? 1 : 0));
+                        q.prio = e.prio + norm2((double)(ux - pv.x(o)), (double)(uy - pv.y(o)));
+                        dst[r] = q;
+                    }
+                }
+            } else {
+                for (int i = 0; i < nset; i++) dist[i] = norm2((double)(ux - pv.x(order[i])), (double)(uy - pv.y(order[i])));
+                for (int i = 1; i < nset; i++) {
+                    const unsigned char o = order[i]; const double dd = dist[i];
+                    int j = i - 1;
+                    while (j >= 0 && dist[j] > dd) { order[j + 1] = order[j]; dist[j + 1] = dist[j]; j--; }
+                    order[j + 1] = o; dist[j + 1] = dd;
+                }
+                for (int i = 0; i < take; i++) { BsEntry q = e; q.push(order[i] + (order[i] >= st ? 1 : 0)); q.prio = e.prio + dist[i]; dst[i] = q; }
+            }
+        }
+        wave_lds_order();
+        BEAM_ACC(29);
+        { BsEntry *tmp = queue; queue = next; next = tmp; }
+        qn = pops * take;
+        if (qn == 0) {  // cannot happen (an incomplete path always has an unvisited point); leave an empty route
+            wave_lds_order();
+            if (t == 0) { BsEntry z; z.prio = 0.0; z.meta = 0ull; z.p0 = 0ull; z.p1 = 0ull; *(BsEntry *)scratch = z; }
+            break;
+        }
+    }
+    wave_lds_order();
+}
+template <bool SMALL>
+__device__ __forceinline__ void beam_routes_lanes(const SegView &v, const PinRec *pins, int nn, int k, unsigned char *beam, int lane, unsigned long long *beam_dbg) {
+    const int groups = NT / BEAM_LANES_PER_NET, gi = lane / BEAM_LANES_PER_NET, t = lane & (BEAM_LANES_PER_NET - 1);
+    for (int n0 = 0; n0 < nn; n0 += groups) {
+        const int n = n0 + gi;
+        if (n >= nn) continue;
+        const int s = v.nstart[n], cnt = v.nstart[n + 1] - s;
+        // pin_outlier: first arg-max of the distance to the centroid (distances one pin per lane in v.D, below)
+        int st = 0; double bd = v.D[s];
+        if (SMALL) {
+            double dd[8];
+            #pragma unroll
+            for (int i = 1; i < 8; i++) dd[i] = v.D[s + (i < cnt ? i : 0)];
+            #pragma unroll
+            for (int i = 1; i < 8; i++) if (i < cnt && dd[i] > bd) { bd = dd[i]; st = i; }
+        } else {
+            for (int i = 1; i < cnt; i++) { const double d = v.D[s + i]; if (d > bd) { bd = d; st = i; } }
+        }
+        beam_route_lanes<SMALL>(v, pins, s, cnt, st, k, beam + (size_t)n * BEAM_LDS_PER_NET(k), t, beam_dbg);
+    }
+}
+// all nets of the environment: v.D / v.act / segment slots are filled with the beam routes
+__device__ __forceinline__ void beam_routes(const SegView &v, const EnvHdr *hdr, const PinRec *pins, int k, unsigned char *beam, int lane, unsigned long long *beam_dbg) {
+    const int np = hdr->npins, nn = hdr->nnets;
+    for (int q = lane; q < np; q += NT) {  // distance of every pin to its net's centroid (v.D is free until the segments are written)
+        const PinRec pr = pins[q];
+        v.D[q] = norm2((double)pr.abs_x - v.cen[pr.net], (double)pr.abs_y - v.cen[PCBENV_MAX_NETS + pr.net]);
+    }
+    lds_sync();
+    // workgroup-uniform: the widest net of this instance decides which build runs (every wavefront looks at all nets)
+    const int nl = lane & 63;
+    const bool wide = __ballot(nl < nn && v.nstart[nl < nn ? nl + 1 : 0] - v.nstart[nl < nn ? nl : 0] > 8) != 0ull;
+    if (!wide && k <= 2) beam_routes_lanes<true>(v, pins, nn, k, beam, lane, beam_dbg);
+    else beam_routes_lanes<false>(v, pins, nn, k, beam, lane, beam_dbg);
+    lds_sync();
+    for (int q = lane; q < np; q += NT) {  // segment i of a net's route = (path[i], path[i + 1]), one slot per lane
+        const int n = pins[q].net, s = v.nstart[n], i = q - s;
+        const BsEntry res = *(const BsEntry *)(beam + (size_t)n * BEAM_LDS_PER_NET(k));
+        const bool act = i + 1 < res.len();
+        if (act) {
+            const PinRec pa = pins[s + res.at(i)], pb = pins[s + res.at(i + 1)];
+            const double x1 = pa.abs_x, y1 = pa.abs_y, x2 = pb.abs_x, y2 = pb.abs_y;
+            v.X1[q] = x1; v.Y1[q] = y1; v.X2[q] = x2; v.Y2[q] = y2;
+            v.D[q] = norm2(x1 - x2, y1 - y2);
+        }
+        v.act[q] = act ? 1 : 0;
+    }
+}
+
 // beam (and, for "both", centroid) routes of the terminal state -> wirelength, #intersections of the chosen route
-__device__ inline void route_beam_or_both(const DevParams &p, const EnvHdr *hdr, const PinRec *pins, double *seg,
+__device__ __forceinline__ void route_beam_or_both(const DevParams &p, const EnvHdr *hdr, const PinRec *pins, double *seg,
                                           int lane, double *wirelength, int *nintersections) {
     const SegView v = seg_view(seg, p.P);
     unsigned char *beam = v.beam;
     net_offsets_and_centroids(v, hdr, pins, lane);
     STAMP(5);
+#ifdef PCBENV_BEAM_SERIAL
     for (int n = lane; n < hdr->nnets; n += NT)
         beam_route_net(v, pins, v.nstart[n], v.nstart[n + 1] - v.nstart[n], p.beam_width, beam + (size_t)n * BEAM_LDS_PER_NET(p.beam_width));
+#else
+    STAMP_ZERO(26); STAMP_ZERO(27); STAMP_ZERO(28); STAMP_ZERO(29);
+    beam_routes(v, hdr, pins, p.beam_width, beam, lane, p.dbg);
+#endif
     lds_sync();
     STAMP(24);
     count_and_length(p, v, hdr, pins, lane, wirelength, nintersections);

@@ -315,7 +315,7 @@ template <int KIND> __device__ inline void emit_features_full(const DevParams &p
 // Terminal reward (S:793-929 find_reward), all three reward types, inside the step kernel.
 // ROUTES = false compiles the beam-search code out (reward_type centroid: what every shipped reference config uses).
 template <int KIND, bool ROUTES>
-__device__ inline void terminal_reward(const DevParams &p, Lds &l, int row, int lane) {
+__device__ __forceinline__ void terminal_reward(const DevParams &p, Lds &l, int row, int lane) {
     const bool placed_all = l.hdr->cur < 0;
     double reward, wl, ni;
     if (!placed_all) {  // S:853-863 worst case: the upper bounds, normalised (spatial: twice, quirk Q3)

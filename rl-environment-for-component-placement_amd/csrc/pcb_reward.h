@@ -159,7 +159,9 @@ __device__ inline void count_finish(const DevParams &p, const SegView &v, int np
     int *total_cnt = v.nstart + PCBENV_MAX_NETS + 1;
     const int np = __builtin_amdgcn_readfirstlane(np_), nn = __builtin_amdgcn_readfirstlane(nn_);
     STAMP(12);
+#ifndef PCBENV_STAMPS_BEAM
     STAMP_ZERO(26); STAMP_ZERO(27); STAMP_ZERO(28); STAMP_ZERO(29);
+#endif
     const int wl_lane = lane & 63, wave = lane >> 6, nwaves = NT / WAVE;
     volatile lds_u16 *buf = (volatile lds_u16 *)(v.pairs + wave * PAIR_ENTRIES_PER_WAVE);  // wave-synchronous: written and read by different lanes
     int cnt = 0, nbuf = 0, step = 0;
@@ -190,14 +192,18 @@ __device__ inline void count_finish(const DevParams &p, const SegView &v, int np
             while (nbuf >= 2 * WAVE) {  // dense batches; the rest (< 128 entries) moves to the front
                 STAMP_T0();
                 cnt += count_candidates(v, buf, 2 * WAVE, wl_lane);
+#ifndef PCBENV_STAMPS_BEAM
                 STAMP_ACC_SINCE(26, cnt); STAMP_ADD(27, 1); STAMP_ADD(28, 2 * WAVE);
+#endif
                 nbuf -= 2 * WAVE;
                 for (int k = wl_lane; k < nbuf; k += WAVE) { const unsigned short rest = buf[2 * WAVE + k]; buf[k] = rest; }
             }
         }
     }
     STAMP(13);
+#ifndef PCBENV_STAMPS_BEAM
     STAMP_ADD(28, nbuf); STAMP_ADD(29, step);
+#endif
     cnt += count_candidates(v, buf, nbuf, wl_lane);
     STAMP(14);
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);

@@ -27,7 +27,7 @@ __device__ inline void presample_next(const DevParams &p, Lds &l, int sampled, i
 // legal mask + observation stream, done, terminal reward, and -- PCBENV_FLAG_AUTO_RESET -- the reset that follows a
 // terminal transition.  State is in LDS (l); outputs go to row `row` of the bound tensors.
 template <int KIND, int WW, bool ROUTES, bool TRAJ>
-__device__ inline void transition(const DevParams &p, Lds &l, int e, int row, int lane, int o, int x, int y) {
+__device__ __forceinline__ void transition(const DevParams &p, Lds &l, int e, int row, int lane, int o, int x, int y) {
     const int H = p.H, W = p.W, plane = H * WW;
     const bool auto_reset = p.flags & PCBENV_FLAG_AUTO_RESET;
     const bool full = TRAJ && p.num_slots > 1;  // trajectory layout: every tensor of the destination slot is written whole

@@ -49,7 +49,9 @@ def report(title, s, done):
                 if (rows[:, x] == 0).all() or (rows[:, y] == 0).all():
                     continue  # a phase this configuration does not run (stamp never written)
                 print(f"    {n:28s} {int(np.median(rows[:, y] - rows[:, x])):7d}")
-            if label == "terminal" and rows[:, 28].any():
+            if label == "terminal" and os.environ.get("PCBENV_STAMPS_BEAM"):
+                print("    beam search, lane 0 (net 0): setup %d, selection %d, expand %d, tie %d cycles" % tuple(int(np.median(rows[:, k])) for k in (26, 27, 28, 29)))
+            elif label == "terminal" and rows[:, 28].any():
                 print(f"    pair count detail: sweep steps {int(np.median(rows[:, 29]))}, candidates after the extent filter "
                       f"{int(np.median(rows[:, 28]))}, in-sweep dense batches {int(np.median(rows[:, 27]))} taking "
                       f"{int(np.median(rows[:, 26]))} cycles")

@@ -224,9 +224,30 @@ template <bool STREAM> __device__ inline void emit_zero_(unsigned char *dst, lon
     }
 }
 __device__ inline void STORE16_dyn(const ObsDst &d, unsigned off, uint4 v, bool stream) { if (stream) STORE16<true>(d, off, v); else STORE16<false>(d, off, v); }
+// The same plane to two destinations (action_mask[o] and action_mask[o + 2] of the pin environments are equal,
+// S:1852-1853): the bits are read and expanded once, stored twice.
+template <int WW, bool STREAM> __device__ inline void emit_plane2_(unsigned char *dst, unsigned char *dst2, const u64 *bits, int H, int W, int lane) {
+    if ((W & 15) == 0 && (((uintptr_t)dst) & 15) == 0 && (((uintptr_t)dst2) & 15) == 0) {
+        const ObsDst d = obs_dst(dst, (long long)H * W), d2 = obs_dst(dst2, (long long)H * W);
+        const int sh = (W & (W - 1)) == 0 ? __ffs(W) - 1 : -1;
+        for (int c = lane; c < H * W / 16; c += NT) {
+            int cell = c * 16, r = sh >= 0 ? cell >> sh : cell / W, col = cell - r * W;
+            unsigned b = (unsigned)(bits[r * WW + (col >> 6)] >> (col & 63)) & 0xFFFFu;
+            const uint4 v = expand16(b);
+            STORE16<STREAM>(d, (unsigned)cell, v);
+            STORE16<STREAM>(d2, (unsigned)cell, v);
+        }
+    } else {
+        emit_plane_<WW, STREAM>(dst, bits, 0, H, W, lane);
+        emit_plane_<WW, STREAM>(dst2, bits, 0, H, W, lane);
+    }
+}
 // the policy is chosen once per plane (wave-uniform branch), not per store
 template <int WW> __device__ inline void emit_plane(unsigned char *dst, const u64 *bits, int r0, int r1, int W, int lane, bool stream) {
     if (stream) emit_plane_<WW, true>(dst, bits, r0, r1, W, lane); else emit_plane_<WW, false>(dst, bits, r0, r1, W, lane);
+}
+template <int WW> __device__ inline void emit_plane2(unsigned char *dst, unsigned char *dst2, const u64 *bits, int H, int W, int lane, bool stream) {
+    if (stream) emit_plane2_<WW, true>(dst, dst2, bits, H, W, lane); else emit_plane2_<WW, false>(dst, dst2, bits, H, W, lane);
 }
 __device__ inline void emit_zero(unsigned char *dst, long long bytes, int lane, bool stream) {
     if (stream) emit_zero_<true>(dst, bytes, lane); else emit_zero_<false>(dst, bytes, lane);

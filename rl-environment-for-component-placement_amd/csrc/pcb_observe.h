@@ -81,7 +81,7 @@ __device__ inline bool mask_and_emit(const DevParams &p, Lds &l, int row, int la
     if (cur >= 0) {
         const int h = l.comps[cur].h, w = l.comps[cur].w;
         any = window_mask<WW>(l.occ, l.hf, l.vm, H, W, h, w, lane, &l.hdr->flag);
-        if (m) { emit_plane<WW>(m, l.vm, 0, H, W, lane, p.stream_stores); if (four) emit_plane<WW>(m + 2 * HW, l.vm, 0, H, W, lane, p.stream_stores); }
+        if (m) { if (four) emit_plane2<WW>(m, m + 2 * HW, l.vm, H, W, lane, p.stream_stores); else emit_plane<WW>(m, l.vm, 0, H, W, lane, p.stream_stores); }
         if (h == w) {
             for (int i = lane; i < plane; i += NT) l.vm[plane + i] = l.vm[i];
             lds_sync();
@@ -91,9 +91,9 @@ __device__ inline bool mask_and_emit(const DevParams &p, Lds &l, int row, int la
     } else {
         for (int i = lane; i < 2 * plane; i += NT) l.vm[i] = 0ull;
         lds_sync();
-        if (m) { emit_plane<WW>(m, l.vm, 0, H, W, lane, p.stream_stores); if (four) emit_plane<WW>(m + 2 * HW, l.vm, 0, H, W, lane, p.stream_stores); }
+        if (m) { if (four) emit_plane2<WW>(m, m + 2 * HW, l.vm, H, W, lane, p.stream_stores); else emit_plane<WW>(m, l.vm, 0, H, W, lane, p.stream_stores); }
     }
-    if (m) { emit_plane<WW>(m + HW, l.vm + plane, 0, H, W, lane, p.stream_stores); if (four) emit_plane<WW>(m + 3 * HW, l.vm + plane, 0, H, W, lane, p.stream_stores); }
+    if (m) { if (four) emit_plane2<WW>(m + HW, m + 3 * HW, l.vm + plane, H, W, lane, p.stream_stores); else emit_plane<WW>(m + HW, l.vm + plane, 0, H, W, lane, p.stream_stores); }
     if (emit) emit_marginals<KIND, WW>(p, l, row, lane);
     return any;
 }

@@ -27,6 +27,7 @@ done
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/prof_c3_fresh -- python3 bench.py --config c3 --instances device --no-cpu-baseline --rollout-steps 0 --repeats 1 > gpurun_out/$R/prof_c3_fresh.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/prof_c3_rollout -- python3 bench.py --config c3 --steps 32 --repeats 1 --no-cpu-baseline --no-fresh-leg > gpurun_out/$R/prof_c3_rollout.log 2>&1
 python bench.py --config c3 --reward both --no-cpu-baseline > gpurun_out/$R/c3_both_bench.json 2>/dev/null
+python bench.py --config c3 --reward beam --no-cpu-baseline > gpurun_out/$R/c3_beam_bench.json 2>/dev/null
 python bench.py --config c3 --loop explicit --no-cpu-baseline > gpurun_out/$R/c3_explicit_bench.json 2>/dev/null
 python bench.py --config c3 --incremental --no-cpu-baseline > gpurun_out/$R/c3_incremental_bench.json 2>/dev/null
 python bench.py --config c4 --incremental --no-cpu-baseline > gpurun_out/$R/c4_incremental_bench.json 2>/dev/null

@@ -809,6 +809,12 @@ def test_presampled_action_is_never_stale():
     ("c3_both_k3", lambda: EnvConfig.pin(64, 64, 9, 9, 2, 6, 2, 6, 16, 16, 8, 8, 6, 6, "both", 3, 0.5), 1024),
     ("c4_centroid", lambda: named_config("c4"), 1024),
     ("pin_ragged_both_k4", lambda: EnvConfig.pin(48, 40, 7, 6, 2, 6, 2, 5, 14, 8, 3, 7, 9, 2, "both", 4, 0.3), 1024),
+    # the beam search's register build at its widest (7-8 pins per net, k = 2) and at k = 1; its wide build with
+    # nets beyond 8 pins; four wavefronts per environment (16 nets x 4 lanes = one wavefront's worth of search lanes)
+    ("pin_8pins_beam_k2", lambda: EnvConfig.pin(64, 64, 9, 9, 2, 6, 2, 6, 16, 16, 4, 6, 8, 7, "beam", 2, 0.5), 512),
+    ("pin_beam_k1", lambda: EnvConfig.pin(64, 64, 9, 9, 2, 6, 2, 6, 16, 16, 8, 8, 6, 3, "beam", 1, 0.5), 512),
+    ("pin_12pins_both_k3", lambda: EnvConfig.pin(64, 64, 9, 9, 3, 6, 3, 6, 16, 16, 3, 4, 12, 9, "both", 3, 0.5), 512),
+    ("c5_beam_k2", lambda: named_config("c5", "beam"), 128),
 ])
 def test_reward_sweep_many_episodes(label, cfg_fn, B):
     """The routing reward is where rare geometry lives (shared end points, parallel segments, equal beam distances):

@@ -330,8 +330,13 @@ def main():
     chunk = max(1, args.chunk) if args.loop == "fused" else 1
     chunk_actions = torch.empty((chunk, B, 3), dtype=torch.int32, device=env.device) if chunk > 1 else None
     adv = torch.randn(16 * B, device=env.device) if (dist and args.adv_allgather) else None
+    adv_stream = None
     if adv is not None:
         from pcbenv.distributed import normalize_advantages
+        # The collective does not depend on the environment steps that follow it (in PPO it belongs to the rollout that
+        # has just ended), so it runs on a side stream and overlaps them; the timed region ends with a device-wide
+        # synchronize, which covers it.
+        adv_stream = torch.cuda.Stream(device=env.device)
 
     def timed_region(step0):
         """EXACTLY args.steps steps between barrier + synchronize on both sides -> (own wall seconds, event ms)."""
@@ -348,7 +353,8 @@ def main():
             for k in range(args.steps):
                 one_step(step0 + k)
                 if adv is not None and k % 16 == 15:  # the PPO-side collective: 64 KiB * B / 1024 per rank over RCCL
-                    normalize_advantages(adv if args.backend == "nccl" else adv.cpu(), "all_gather")
+                    with torch.cuda.stream(adv_stream):
+                        normalize_advantages(adv if args.backend == "nccl" else adv.cpu(), "all_gather")
         ev[1].record()
         torch.cuda.synchronize()
         if dist:

@@ -256,8 +256,27 @@ __device__ inline void emit_zero(unsigned char *dst, long long bytes, int lane, 
 // Legal-placement bit mask for a ph x pw window (R:526-567, S:1792-1835):
 // vm[r] bit j = 1 iff r <= H-ph and j <= W-pw and occ[r..r+ph-1][j..j+pw-1] is empty.
 // Returns (wave-uniform) whether any bit is set.
+// value of `a` held by lane + s (0 beyond the wavefront): one cross-lane read per 32-bit half
+__device__ inline u64 lane_down(u64 a, int s, int lane) {
+    const int src = (lane + s) << 2;
+    const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned)a), hi = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned)(a >> 32));
+    return lane + s < WAVE ? (((u64)hi << 32) | lo) : 0ull;
+}
 template <int WW>
 __device__ inline bool window_mask(const u64 *occ, u64 *hf, u64 *vm, int H, int W, int ph, int pw, int lane, unsigned *flag) {
+#ifndef PCBENV_FOLD_LDS
+    if (WW == 1 && NT == WAVE && H <= WAVE) {
+        // One row per lane: the vertical OR over ph rows by log-step doubling across lanes, like the horizontal one across
+        // bits -- no staging of the folded rows in LDS, no barrier, at most three cross-lane steps for ph <= 8.
+        u64 a = lane < H ? hfold<1>(Row<1>::load(occ + lane), pw).a : 0ull;
+        int s = 1;
+        while (2 * s <= ph) { a |= lane_down(a, s, lane); s *= 2; }
+        if (s < ph) a |= lane_down(a, ph - s, lane);
+        const u64 v = (lane + ph <= H) ? Row<1>{a}.free_below(W - pw + 1).a : 0ull;
+        if (lane < H) vm[lane] = v;
+        return __any(v != 0ull);
+    }
+#endif
     for (int r = lane; r < H; r += NT) hfold<WW>(Row<WW>::load(occ + r * WW), pw).store(hf + r * WW);
     lds_sync();
     bool any = false;

@@ -28,7 +28,20 @@ __device__ inline Lds carve(unsigned char *smem, const DevParams &p) {
 __device__ inline void load_state(unsigned char *smem, const DevParams &p, int e, int lane) {
     const uint4 *src = (const uint4 *)(p.state + (size_t)e * p.stateStride);
     uint4 *dst = (uint4 *)smem;
-    for (int i = lane; i < (int)(p.stateStride / 16); i += NT) dst[i] = src[i];
+    const int n = (int)(p.stateStride / 16);
+    if (n <= NT) {  // small blocks (c2): one chunk per lane
+        if (lane < n) dst[lane] = src[lane];
+    } else {
+        // Every wavefront of the launch starts here: all of a lane's chunks are requested before the first one is awaited
+        // (one memory round trip for the block instead of one per 1 KiB), up to four per lane (c3 / c4: 3, c5: 2), a plain
+        // loop beyond.
+        uint4 t[4];
+        #pragma unroll
+        for (int k = 0; k < 4; k++) { const int i = lane + k * NT; t[k] = i < n ? src[i] : make_uint4(0, 0, 0, 0); }
+        #pragma unroll
+        for (int k = 0; k < 4; k++) { const int i = lane + k * NT; if (i < n) dst[i] = t[k]; }
+        for (int i = lane + 4 * NT; i < n; i += NT) dst[i] = src[i];
+    }
     lds_sync();
 }
 __device__ inline void store_state(const unsigned char *smem, const DevParams &p, int e, int lane) {
@@ -127,11 +140,24 @@ template <int WW> __device__ inline void emit_pin_grid(const DevParams &p, Lds &
                 int cell = (int)__umulhi((unsigned)bb, kinv);
                 if (cell * K > bb) cell--;  // (never taken at these sizes; keeps the division exact regardless)
                 u64 lo = 0, hi = 0;
-                for (int base = cell * K; base < bb + 16 && cell < c1; base += K, cell++) {
-                    const unsigned cl = l.cls[cell];
-                    const int off = base + (int)cl - 1 - bb;  // byte of this cell's 1 inside the chunk
-                    if (cl != 0 && off >= 0 && off < 16) {
-                        if (off < 8) lo |= 1ull << (8 * off); else hi |= 1ull << (8 * (off - 8));
+                if (K >= 5) {  // a chunk overlaps at most ceil((15 + K) / K) <= 4 cells: their classes are read together (one LDS round trip per store, not one per cell)
+                    unsigned cl[4];
+                    #pragma unroll
+                    for (int j = 0; j < 4; j++) cl[j] = cell + j < c1 ? (unsigned)l.cls[cell + j] : 0u;
+                    #pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int off = (cell + j) * K + (int)cl[j] - 1 - bb;  // byte of this cell's 1 inside the chunk
+                        if (cl[j] != 0 && off >= 0 && off < 16) {
+                            if (off < 8) lo |= 1ull << (8 * off); else hi |= 1ull << (8 * (off - 8));
+                        }
+                    }
+                } else {
+                    for (int base = cell * K; base < bb + 16 && cell < c1; base += K, cell++) {
+                        const unsigned cl = l.cls[cell];
+                        const int off = base + (int)cl - 1 - bb;  // byte of this cell's 1 inside the chunk
+                        if (cl != 0 && off >= 0 && off < 16) {
+                            if (off < 8) lo |= 1ull << (8 * off); else hi |= 1ull << (8 * (off - 8));
+                        }
                     }
                 }
                 STORE16<decltype(stream_tag)::value>(d, (unsigned)bb, make_uint4((unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)));

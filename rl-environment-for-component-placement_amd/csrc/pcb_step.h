@@ -31,20 +31,21 @@ __device__ __forceinline__ void transition(const DevParams &p, Lds &l, int e, in
     const int H = p.H, W = p.W, plane = H * WW;
     const bool auto_reset = p.flags & PCBENV_FLAG_AUTO_RESET;
     const bool full = TRAJ && p.num_slots > 1;  // trajectory layout: every tensor of the destination slot is written whole
-    const int cur = l.hdr->cur;
+    const int cur = l.hdr->cur, ncomp = l.hdr->ncomp, npins = l.hdr->npins;
     // validate_action (S:1699-1723): action_mask[o, x, y] == 1; anything out of range is invalid
     bool valid = o >= 0 && o < p.O && x >= 0 && x < H && y >= 0 && y < W && (KIND == PCBENV_SQUARE || cur >= 0);
     if (valid) valid = (l.vm[(o & 1) * plane + x * WW + (y >> 6)] >> (y & 63)) & 1ull;
 
     if (lane == 0 && p.buf.info) { p.buf.info[2 * (size_t)row] = nan(""); p.buf.info[2 * (size_t)row + 1] = nan(""); }
-    lds_sync();
+    if (NT > WAVE) lds_sync();  // every wavefront has read the cursor before wavefront 0 advances it (one wavefront: program order)
 
     bool done = true;  // an invalid action is a terminal transition with state and observations unchanged (quirk Q8 iii)
     if (valid) {
         int ph, pw;
+        CompRec cr = CompRec();
         if (KIND == PCBENV_SQUARE) ph = pw = p.component_n;
         else {
-            const CompRec cr = l.comps[cur];
+            cr = l.comps[cur];
             ph = (o & 1) ? cr.w : cr.h;  // S:1742-1747 update_grid
             pw = (o & 1) ? cr.h : cr.w;
         }
@@ -58,8 +59,8 @@ __device__ __forceinline__ void transition(const DevParams &p, Lds &l, int e, in
         if (KIND != PCBENV_SQUARE) {
             if (lane == 0) { l.comps[cur].px = (signed char)x; l.comps[cur].py = (signed char)y; l.comps[cur].o = (unsigned char)o; }
             if (KIND == PCBENV_PIN || KIND == PCBENV_SPATIAL) {
-                const int ch = l.comps[cur].h, cw = l.comps[cur].w;
-                for (int q = lane; q < l.hdr->npins; q += NT) {  // S:149-190 place_component
+                const int ch = cr.h, cw = cr.w;
+                for (int q = lane; q < npins; q += NT) {  // S:149-190 place_component
                     PinRec pr = l.pins[q];
                     if (pr.comp != cur) continue;
                     const int rx = pr.rel_x, ry = pr.rel_y;
@@ -72,7 +73,7 @@ __device__ __forceinline__ void transition(const DevParams &p, Lds &l, int e, in
                 }
             }
             if (lane == 0) {
-                const int next = cur + 1 < l.hdr->ncomp ? cur + 1 : -1;
+                const int next = cur + 1 < ncomp ? cur + 1 : -1;
                 if (!full) {
                     if (p.buf.all_components_feature) {
                         double *cf = p.buf.all_components_feature + ((size_t)row * p.C + cur) * p.F;

@@ -119,9 +119,17 @@ template <int WW> __device__ inline void emit_pin_grid(const DevParams &p, Lds &
     const int c0 = r0 * W, c1 = r1 * W;
     unsigned char *dst = p.buf.pin_grid + (size_t)row * HW * K;
     const long long b0 = (long long)c0 * K, b1 = (long long)c1 * K;
-    for (int i = c0 + lane; i < c1; i += NT) {
-        int r = i / W, c = i - r * W;
-        l.cls[i] = (unsigned char)((l.occ[r * WW + (c >> 6)] >> (c & 63)) & 1ull);
+    if ((W & 15) == 0) {  // sixteen cells per lane and trip: one occupancy word read, one 16-byte write (was: a read, a division and a byte per cell)
+        const int sh = (W & (W - 1)) == 0 ? __ffs(W) - 1 : -1;
+        for (int ch = c0 / 16 + lane; ch < c1 / 16; ch += NT) {
+            const int cell = ch * 16, r = sh >= 0 ? cell >> sh : cell / W, c = cell - r * W;
+            *(uint4 *)(l.cls + cell) = expand16((unsigned)(l.occ[r * WW + (c >> 6)] >> (c & 63)) & 0xFFFFu);
+        }
+    } else {
+        for (int i = c0 + lane; i < c1; i += NT) {
+            int r = i / W, c = i - r * W;
+            l.cls[i] = (unsigned char)((l.occ[r * WW + (c >> 6)] >> (c & 63)) & 1ull);
+        }
     }
     lds_sync();
     for (int q = lane; q < l.hdr->npins; q += NT) {

@@ -181,7 +181,12 @@ template <bool STREAM> __device__ inline void STORE16(const ObsDst &d, unsigned 
 struct ObsDst { __amdgpu_buffer_rsrc_t rsrc; };
 // base must be wave-uniform (it is: tensor pointer + blockIdx.x * per-environment bytes)
 __device__ inline ObsDst obs_dst(unsigned char *base, long long bytes) {
-    return ObsDst{__builtin_amdgcn_make_buffer_rsrc(base, 0, (int)bytes, 0x00020000)};
+    // The descriptor has to sit in scalar registers.  Where the compiler cannot prove base / bytes uniform it wraps every
+    // store in a "waterfall" loop (readfirstlane x 4, compare, saveexec, branch -- per store); they ARE uniform, say so.
+    const uintptr_t b = (uintptr_t)base;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
+    unsigned char *ub = (unsigned char *)(((uintptr_t)hi << 32) | lo);
+    return ObsDst{__builtin_amdgcn_make_buffer_rsrc(ub, 0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000)};
 }
 #define PCBENV_AUX_SC1 16
 #define PCBENV_AUX_NT 2

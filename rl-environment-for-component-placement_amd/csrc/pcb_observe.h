@@ -152,12 +152,13 @@ template <int WW> __device__ inline void emit_pin_grid(const DevParams &p, Lds &
                     unsigned cl[4];
                     #pragma unroll
                     for (int j = 0; j < 4; j++) cl[j] = cell + j < c1 ? (unsigned)l.cls[cell + j] : 0u;
+                    const int rel = cell * K - bb - 1;  // byte of cell j's 1 inside the chunk: rel + j * K + class
                     #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const int off = (cell + j) * K + (int)cl[j] - 1 - bb;  // byte of this cell's 1 inside the chunk
-                        if (cl[j] != 0 && off >= 0 && off < 16) {
-                            if (off < 8) lo |= 1ull << (8 * off); else hi |= 1ull << (8 * (off - 8));
-                        }
+                    for (int j = 0; j < 4; j++) {  // branch-free: one 64-bit shift and two selects per cell
+                        const unsigned off = (unsigned)(rel + j * K + (int)cl[j]);
+                        const u64 m = (u64)(cl[j] != 0 && off < 16u) << ((off & 7u) * 8u);
+                        lo |= (off & 8u) ? 0ull : m;
+                        hi |= (off & 8u) ? m : 0ull;
                     }
                 } else {
                     for (int base = cell * K; base < bb + 16 && cell < c1; base += K, cell++) {

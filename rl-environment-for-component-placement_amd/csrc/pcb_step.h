@@ -170,8 +170,10 @@ __global__ __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(64 * NW)
         int o = 0, x = 0, y = 0;
         int *act = actions + per_step * (size_t)t;
         if (sampled) {
-            const unsigned pa = l.hdr->pre_action;
-            if (t == 0 && (pa >> 31) && l.hdr->pre_seed == seed && l.hdr->pre_step == step_index && l.hdr->pre_genv == (unsigned)genv) {
+            // the tag is read whole before it is tested: `&&` would chain four dependent LDS round trips at the head of every launch
+            const unsigned pa = l.hdr->pre_action, pg = l.hdr->pre_genv;
+            const u64 ps = l.hdr->pre_seed, pst = l.hdr->pre_step;
+            if ((t == 0) & (pa >> 31) & (ps == seed) & (pst == step_index) & (pg == (unsigned)genv)) {
                 o = (int)(pa & 0xFFu); x = (int)((pa >> 8) & 0xFFu); y = (int)((pa >> 16) & 0xFFu);  // drawn by the previous launch
                 STAMP(21);
             } else {

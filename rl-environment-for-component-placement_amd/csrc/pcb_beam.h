@@ -10,7 +10,8 @@
 // Objects/setobject.c's open-addressing table (SURVEY.md trap T2).  That order can only change WHICH points are
 // kept when the beam_width-th and the next distance tie (the order among kept neighbours is irrelevant: heapq
 // pops by (priority, path), not by insertion).  So the set model below runs only on such boundary ties.
-// One lane per net; all per-net scratch lives in LDS (no private-memory arrays -> no scratch segment).
+// Four lanes per net (one per heappop of a level, see "laid out for latency" below); all per-net scratch lives in LDS
+// (no private-memory arrays -> no scratch segment).
 #define CS_EMPTY 0xFF
 #define CS_DUMMY 0xFE
 #define BS_MAXPTS (PCBENV_MAX_PINS_PER_NET - 1)
@@ -144,116 +145,6 @@ __device__ inline int cs_difference_order(CSet *A, CSet *R, int m, unsigned visi
     return n;
 }
 
-#ifdef PCBENV_BEAM_SERIAL
-// One net, one lane: fills the net's slots [s, s+cnt) of the segment view with the beam route.
-// `scratch` = this net's BEAM_LDS_PER_NET(k) bytes of LDS.
-__device__ inline void beam_route_net(const SegView &v, const PinRec *pins, int s, int cnt, int k, unsigned char *scratch) {
-    BsEntry *queue = (BsEntry *)scratch, *next = queue + k * k;
-    double *dist = (double *)(scratch + 64 * k * k);
-    unsigned char *order = (unsigned char *)(dist + 16);
-    CSet *A = (CSet *)(order + 16), *R = A + 1;
-    const double cx = v.cen[pins[s].net], cy = v.cen[PCBENV_MAX_NETS + pins[s].net];
-    int st = 0; double bd = 0.0;  // pin_outlier: first arg-max of the distance to the centroid
-    for (int i = 0; i < cnt; i++) {
-        const double d = norm2((double)pins[s + i].abs_x - cx, (double)pins[s + i].abs_y - cy);
-        if (i == 0 || d > bd) { bd = d; st = i; }
-    }
-    const int sx = pins[s + st].abs_x, sy = pins[s + st].abs_y;
-    const int m = cnt - 1;
-    const NetPts pt = NetPts::load(pins + s, cnt, st);
-    const unsigned all = (1u << m) - 1u;
-    int qn = 1;
-    { BsEntry e0; e0.prio = 0.0; e0.meta = 1ull << 16; e0.p0 = 0xFFull; e0.p1 = 0ull; queue[0] = e0; }
-    bool found = false;
-    BsEntry res;
-    while (!found) {
-        int nn = 0;
-        unsigned taken = 0;
-        const int pops = k < qn ? k : qn;
-        for (int t = 0; t < pops && !found; t++) {
-            int best = -1;  // heappop: minimum (priority, path) of what is left
-            BsEntry e;
-            for (int i = 0; i < qn; i++) {
-                if (taken >> i & 1u) continue;
-                const BsEntry a = queue[i];
-                bool less;
-                if (best < 0) less = true;
-                else if (a.prio != e.prio) less = a.prio < e.prio;
-                else {  // equal priorities: python compares the path lists of (x, y) tuples
-                    less = a.len() < e.len();
-                    const int n = a.len() < e.len() ? a.len() : e.len();
-                    for (int j = 0; j < n; j++) {
-                        const int pa = a.at(j), pb = e.at(j);
-                        const int ax = pa == 0xFF ? sx : pt.x(pa), ay = pa == 0xFF ? sy : pt.y(pa);
-                        const int bx = pb == 0xFF ? sx : pt.x(pb), by = pb == 0xFF ? sy : pt.y(pb);
-                        if (ax != bx) { less = ax < bx; break; }
-                        if (ay != by) { less = ay < by; break; }
-                    }
-                }
-                if (less) { best = i; e = a; }
-            }
-            taken |= 1u << best;
-            if (e.visited() == all) { found = true; res = e; break; }
-            const int cur = e.at(e.len() - 1);
-            const int ux = cur == 0xFF ? sx : pt.x(cur), uy = cur == 0xFF ? sy : pt.y(cur);
-            // the k+1 nearest unvisited points in registers (ascending distance, index order among equals)
-            double td[PCBENV_MAX_BEAM_WIDTH + 1]; int ti[PCBENV_MAX_BEAM_WIDTH + 1];
-            #pragma unroll
-            for (int q = 0; q <= PCBENV_MAX_BEAM_WIDTH; q++) { td[q] = 0.0; ti[q] = 0; }
-            int nfill = 0, cntn = 0;
-            for (int i = 0; i < m; i++) {
-                if (e.visited() >> i & 1u) continue;
-                cntn++;
-                double cd = norm2((double)(ux - pt.x(i)), (double)(uy - pt.y(i)));
-                int ci = i;
-                bool shifting = false, placed = false;
-                #pragma unroll
-                for (int q = 0; q <= PCBENV_MAX_BEAM_WIDTH; q++) {
-                    if (q > k || placed) continue;
-                    if (q == nfill) { td[q] = cd; ti[q] = ci; placed = true; }
-                    else if (shifting || td[q] > cd) {
-                        const double xd = td[q]; const int xi = ti[q];
-                        td[q] = cd; ti[q] = ci; cd = xd; ci = xi; shifting = true;
-                    }
-                }
-                if (nfill <= k) nfill++;
-            }
-            const int take = cntn < k ? cntn : k;
-            bool tie = false;
-            #pragma unroll
-            for (int q = 1; q <= PCBENV_MAX_BEAM_WIDTH; q++) if (q == k && cntn > k) tie = td[q - 1] == td[q];
-            if (tie) {  // boundary tie: the CPython set order decides who is kept
-                const int nset = cs_difference_order(A, R, m, e.visited(), pt, order);
-                for (int i = 0; i < nset; i++) dist[i] = norm2((double)(ux - pt.x(order[i])), (double)(uy - pt.y(order[i])));
-                for (int i = 1; i < nset; i++) {  // sorted(key=distance): stable
-                    const unsigned char o = order[i]; const double d = dist[i];
-                    int j = i - 1;
-                    while (j >= 0 && dist[j] > d) { order[j + 1] = order[j]; dist[j + 1] = dist[j]; j--; }
-                    order[j + 1] = o; dist[j + 1] = d;
-                }
-                for (int i = 0; i < take; i++) { BsEntry q = e; q.push(order[i]); q.prio = e.prio + dist[i]; next[nn++] = q; }
-            } else {
-                #pragma unroll
-                for (int q = 0; q < PCBENV_MAX_BEAM_WIDTH; q++)
-                    if (q < take) { BsEntry w = e; w.push(ti[q]); w.prio = e.prio + td[q]; next[nn++] = w; }
-            }
-        }
-        if (!found) { BsEntry *tmp = queue; queue = next; next = tmp; qn = nn; if (qn == 0) break; }
-    }
-    for (int i = 0; i < cnt; i++) v.act[s + i] = 0;
-    if (!found) return;
-    for (int i = 0; i + 1 < res.len(); i++) {
-        const int a = res.at(i), b = res.at(i + 1);
-        const double x1 = a == 0xFF ? sx : pt.x(a), y1 = a == 0xFF ? sy : pt.y(a);
-        const double x2 = b == 0xFF ? sx : pt.x(b), y2 = b == 0xFF ? sy : pt.y(b);
-        v.X1[s + i] = x1; v.Y1[s + i] = y1; v.X2[s + i] = x2; v.Y2[s + i] = y2;
-        v.D[s + i] = norm2(x1 - x2, y1 - y2);
-        v.act[s + i] = 1;
-    }
-}
-
-#endif
-
 // ---- boundary ties, fast path ------------------------------------------------------------------------------
 // `A = set(points)` and the tuple hashes depend on the net only: built once per net (first tie) and kept in LDS.
 // (Low 32 bits of each hash: they carry the first five perturb steps of an 8-slot walk; a longer walk -- occupied slots
@@ -314,8 +205,8 @@ __device__ inline int cs_small_difference_order(const CSet *A, const unsigned *h
 //    monotone on it, so the order (and the boundary tie) is the reference's; only the priorities need float64 norms;
 //  * the farthest-from-centroid start pin and the route segments are computed one pin per lane before / after;
 //  * the rare boundary tie still runs the serial CPython-set model, the lanes of a net taking turns (shared scratch).
-// Same results as the one-lane-per-net search (kept under -DPCBENV_BEAM_SERIAL for A/B runs): same pop order (first
-// index among fully equal entries), same children in the same queue order.
+// Same results as round 1's one-lane-per-net search (git history): same pop order (first index among fully equal
+// entries), same children in the same queue order.
 #define BEAM_LANES_PER_NET PCBENV_MAX_BEAM_WIDTH
 #if defined(PCBENV_STAMPS) && defined(PCBENV_STAMPS_BEAM)  // phase cycles of the search, accumulated by lane 0 into stamp slots 26..29
 #define BEAM_T0() unsigned long long bt0_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(bt0_) :: "memory")
@@ -480,9 +371,6 @@ __device__ __forceinline__ void beam_route_lanes(const SegView &v, const PinRec 
         bool tie = false;
         #pragma unroll
         for (int q = 1; q <= PCBENV_MAX_BEAM_WIDTH; q++) if (q == k && cntn > k) tie = (chosen[q - 1] >> 4) == (chosen[q] >> 4);
-#ifdef PCBENV_BEAM_NOTIE  // diagnostic only (wrong on boundary ties): what the search costs without the set model
-        tie = false;
-#endif
         BsEntry *dst = next + t * take;
         if (worker && !tie) {
             #pragma unroll
@@ -614,13 +502,8 @@ __device__ __forceinline__ void route_beam_or_both(const DevParams &p, const Env
     unsigned char *beam = v.beam;
     net_offsets_and_centroids(v, hdr, pins, lane);
     STAMP(5);
-#ifdef PCBENV_BEAM_SERIAL
-    for (int n = lane; n < hdr->nnets; n += NT)
-        beam_route_net(v, pins, v.nstart[n], v.nstart[n + 1] - v.nstart[n], p.beam_width, beam + (size_t)n * BEAM_LDS_PER_NET(p.beam_width));
-#else
     STAMP_ZERO(26); STAMP_ZERO(27); STAMP_ZERO(28); STAMP_ZERO(29);
     beam_routes(v, hdr, pins, p.beam_width, beam, lane, p.dbg);
-#endif
     lds_sync();
     STAMP(24);
     count_and_length(p, v, hdr, pins, lane, wirelength, nintersections);

@@ -520,14 +520,7 @@ __global__ __launch_bounds__(WAVE) void k_gen_seed(GenParams c, const unsigned *
 // read them with agent-scope loads.  The grid is capped (GEN_MAX_GRID): a wavefront walks over several batches of
 // environments, so that the generator never holds more than a few wavefront slots per CU next to the step kernels.
 template <int G>
-#ifndef GEN_WAVES_PER_EU_MIN
-#define GEN_WAVES_PER_EU_MIN 4
-#endif
-#ifdef GEN_NUM_VGPR
-__global__ __attribute__((amdgpu_num_vgpr(GEN_NUM_VGPR))) __launch_bounds__(WAVE) void k_gen_fill(GenParams c) {
-#else
-__global__ __attribute__((amdgpu_waves_per_eu(GEN_WAVES_PER_EU_MIN, 8))) __launch_bounds__(WAVE) void k_gen_fill(GenParams c) {
-#endif
+__global__ __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(WAVE) void k_gen_fill(GenParams c) {
     extern __shared__ __attribute__((aligned(16))) unsigned char gen_smem[];
     constexpr int EPW = WAVE / G;
     const int lane = threadIdx.x, grp = lane / G, gl = lane & (G - 1);

@@ -37,6 +37,7 @@ struct pcbenv {
     DevParams dp;
     bool bound;
     int threads;  // workgroup size (threads per environment)
+    long long cell_bytes_per_env, stream_threshold;  // store policy (see STORE16): cell-tensor bytes one transition writes per environment
     unsigned *scratch;  // 16 bytes of device memory for small read-backs
     unsigned long long loaded_slots[4];  // bit s = slot s loaded for all environments at least once
     // on-device instance generator (pcbenv_instgen_device_enable): side stream + the bookkeeping that guarantees a
@@ -181,6 +182,7 @@ extern "C" int pcbenv_create(const pcbenv_config *cfg, int device, pcbenv **out)
         long long threshold_mb = 256;
         if (const char *ev = getenv("PCBENV_STREAM_THRESHOLD_MB")) threshold_mb = atoll(ev);
         d.stream_stores = per_env * c.num_envs > threshold_mb * (1ll << 20);
+        env->cell_bytes_per_env = per_env; env->stream_threshold = threshold_mb * (1ll << 20);
     }
     d.w_wl = c.weight_wirelength; d.w_int = c.weight_num_intersections;
     d.area = (double)(c.height * c.width);
@@ -351,9 +353,16 @@ template <int KIND> static int launch_reset(pcbenv *env, const uint8_t *mask, hi
 }
 template <int KIND> static int launch_step(pcbenv *env, int *actions, int fmt, int sampled, u64 seed, u64 first_env,
                                            u64 step_index, int num_steps, hipStream_t s) {
-    const DevParams &d = env->dp;
+    DevParams d = env->dp;
     // lean build (in-place layout, one transition, store policy compiled in) or the trajectory / rollout build
     const bool traj = d.num_slots > 1 || num_steps > 1;
+    // A persistent rollout into the trajectory layout writes min(num_steps, num_slots) slots per launch, none of which is
+    // read before the launch ends: the policy is chosen on what the LAUNCH writes (in place, the steps of a rollout
+    // overwrite the same lines and the per-transition choice of pcbenv_create stands).
+    if (traj && d.num_slots > 1) {
+        const long long slots = num_steps < d.num_slots ? num_steps : d.num_slots;
+        d.stream_stores = env->cell_bytes_per_env * d.B * slots > env->stream_threshold;
+    }
 #define LAUNCH_STEP_(WW_, NW_, RT_, ST_, TJ_) hipLaunchKernelGGL((k_step<KIND, WW_, NW_, RT_, ST_, TJ_>), dim3(d.B), dim3(64 * NW_), d.ldsBytes, s, d, actions, fmt, sampled, seed, first_env, step_index, num_steps)
 #define LAUNCH_STEP(WW_, NW_, RT_) do { if (traj) LAUNCH_STEP_(WW_, NW_, RT_, false, true); else if (d.stream_stores) LAUNCH_STEP_(WW_, NW_, RT_, true, false); else LAUNCH_STEP_(WW_, NW_, RT_, false, false); } while (0)
     constexpr bool PINK = (KIND == PCBENV_PIN || KIND == PCBENV_SPATIAL);

@@ -117,6 +117,7 @@ class BatchedPlacementEnv:
         self._last_done = self.done  # `done` of the latest step (it may live in another slot than the selected one)
         self._streams: Optional[List[InstanceStream]] = None
         self._native = None
+        self.device_instances = False  # True once the on-device generator owns the queue (enable_device_instances)
         torch.cuda.synchronize(self.device)
 
     # -- lifetime ---------------------------------------------------------------------------
@@ -155,7 +156,13 @@ class BatchedPlacementEnv:
         packed = np.ascontiguousarray(pack_instances(self.cfg, instances))
         self.load_packed(packed, slot, env_ids)
 
+    def _host_queue_only(self, what: str):
+        if self.device_instances:
+            raise RuntimeError(f"{what}: the on-device generator owns the instance queue (enable_device_instances); "
+                               "host-side records can no longer be queued")
+
     def load_packed(self, packed: np.ndarray, slot: int = 0, env_ids: Optional[Sequence[int]] = None):
+        self._host_queue_only("load_instances")
         ids = None if env_ids is None else np.ascontiguousarray(env_ids, np.int32)
         _lib.check(self._L.pcbenv_load_instances(
             self._h, None if ids is None else ids.ctypes.data, packed.shape[0], slot, packed.ctypes.data,
@@ -170,6 +177,7 @@ class BatchedPlacementEnv:
         Returns the packed records per slot (uint8 [B, instance_stride])."""
         if self.cfg.kind == KIND_SQUARE:
             return []
+        self._host_queue_only("generate_instances")
         mode = ("native", bool(verify)) if native else ("numpy", False)
         if getattr(self, "_gen_mode", mode) != mode:
             raise RuntimeError("generate_instances: keep the same generator (native / verify) for the lifetime of the "
@@ -226,6 +234,7 @@ class BatchedPlacementEnv:
         about to read that slot, e.g. between rollouts; copies are ordered on the current stream)."""
         if self.cfg.kind == KIND_SQUARE:
             return None
+        self._host_queue_only("refill_slot")
         if native:
             if self._native is None:
                 raise RuntimeError("call generate_instances(native=True) first")

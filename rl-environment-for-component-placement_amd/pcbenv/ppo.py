@@ -106,11 +106,13 @@ class PPOTrainer:
         adv = normalize_advantages(batch["adv"].reshape(N), self.cfg.adv_mode)  # global mean / std over all ranks
         # BatchNorm: the rollout computed logp0 with the running statistics, so the surrogate ratio must use them too
         # (its first-epoch value is then exactly 1); the statistics themselves are refreshed once per iteration from
-        # a minibatch in training mode, averaged over the ranks.
+        # a RANDOM minibatch in training mode (a leading slice would be the first timesteps of every environment: mostly
+        # empty boards), averaged over the ranks.
         with torch.no_grad():
             self.policy.train()
-            self.policy({k: o[:max(1, N // self.cfg.minibatches)] for k, o in flat_obs.items()})
-            allreduce_mean_([b for b in self.policy.buffers()])
+            ridx = torch.randperm(N, device=act.device)[:max(1, N // self.cfg.minibatches)]
+            self.policy({k: o[ridx] for k, o in flat_obs.items()})
+            allreduce_mean_([b for b in self.policy.buffers() if b.is_floating_point()])
         self.policy.eval()
         stats = {}
         for _ in range(self.cfg.epochs):

@@ -75,7 +75,11 @@ class SingleEnvAdapter:
     def _obs(self) -> Dict[str, np.ndarray]:
         return {k: v[0].cpu().numpy().astype(self._dtype) for k, v in self._env.obs.items()}
 
-    def reset(self, instance: Optional[Instance] = None, verbose: bool = False) -> Dict[str, np.ndarray]:
+    def reset(self, verbose: bool = False, *args, instance: Optional[Instance] = None, **kwargs) -> Dict[str, np.ndarray]:
+        """`reset(verbose=False, *args, **kwargs)` like the reference (S:1487; `verbose` is its first positional and is
+        ignored here as there is nothing to print); `instance=` (keyword only) replaces the next instance of the stream."""
+        if isinstance(verbose, Instance):
+            raise TypeError("pass the instance by keyword: reset(instance=...) -- the first positional argument is the reference's `verbose`")
         if self.cfg.kind != KIND_SQUARE:
             self.instance = instance if instance is not None else self._stream.next()
             self._env.load_instances([self.instance])

@@ -18,7 +18,8 @@ action-independent.  Per case it stores, in `tests/golden/<case>.npz`:
 * per step the action, reward (float64), done, info values,
 * the full observation after reset and after every step (0/1 arrays bit-packed).
 
-Also written: `spaces.json` (the gym spaces every reference constructor declares), `adapter_views.npz` (`env.components`
+Also written: `spaces.json` (the gym spaces every reference constructor declares), `model_config_spatial.json` (the
+shipped hyper-parameters of the spatial policy, a data file of the reference), `adapter_views.npz` (`env.components`
 with all pin coordinates after whole episodes), `norm2.npz` (np.linalg.norm of length-2 vectors in this container's
 NumPy/OpenBLAS -- SURVEY.md trap T1) and `setorder.npz` (CPython iteration order of
 `set(points) - visited` -- trap T2).  The files are data only; no reference source
@@ -258,7 +259,20 @@ def record_adapter_views():
     np.savez_compressed(os.path.join(HERE, "adapter_views.npz"), **data)
 
 
+def record_model_config():
+    """The hyper-parameters the reference ships for the spatial policy (`agent/config/rectangle_pin_spatial_model.json`,
+    a data file): `tests/golden/model_config_spatial.json`, compared with pcbenv/policy.py's defaults by
+    tests/test_policy_cpu.py."""
+    with open("/root/reference/agent/config/rectangle_pin_spatial_model.json") as f:
+        ref = json.load(f)
+    with open(os.path.join(HERE, "model_config_spatial.json"), "w") as f:
+        json.dump({"env_config": ref["env_config"], "custom_model_config": ref["model"]["custom_model_config"]}, f, indent=1, sort_keys=True)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "model_config":  # only the (tiny) model-config fixture
+        record_model_config()
+        raise SystemExit(0)
     total = 0
     for case in CASES:
         sz = record_case(*case)
@@ -268,4 +282,5 @@ if __name__ == "__main__":
     record_setorder()
     record_spaces()
     record_adapter_views()
+    record_model_config()
     print(f"total {total / 1024:.1f} KiB")

@@ -72,7 +72,7 @@ def rect_scenarios(make):
     cfg = EnvConfig.rect(6, 6, 2, 4, 2, 4, 4, 1)
     two = inst([(1, 2), (3, 2)])
     env = make(cfg)
-    obs = env.reset(two)
+    obs = env.reset(instance=two)
     m = obs["action_mask"]                        # test_env.py:182-201 test_validate_action
     assert m[0, 0, 0] == 1 and m[0, 4, 5] == 0 and m[1, 2, 3] == 1 and m[1, 5, 4] == 0
     # test_components.py:27-50: [h, w, -1, -1, area ratio]
@@ -89,13 +89,13 @@ def rect_scenarios(make):
     assert obs["action_mask"][0, 3, 4] == 1
     # :204-228 test_compute_action_mask: after (0,0,0),(0,2,3) a 2x2 cannot go at (2,3) but can at (4,0)
     env = make(cfg)
-    env.reset(inst([(1, 2), (3, 2), (2, 2)]))
+    env.reset(instance=inst([(1, 2), (3, 2), (2, 2)]))
     env.step((0, 0, 0))
     obs, r, d, _ = env.step((0, 2, 3))
     assert obs["action_mask"][0, 2, 3] == 0 and obs["action_mask"][0, 4, 0] == 1 and not d
     # :231-254 orientation 1 of a 4x2 after (0,0,0),(0,1,2)
     env = make(cfg)
-    env.reset(inst([(1, 2), (3, 2), (4, 2)]))
+    env.reset(instance=inst([(1, 2), (3, 2), (4, 2)]))
     env.step((0, 0, 0))
     obs, _, _, _ = env.step((0, 1, 2))
     assert obs["action_mask"][1, 1, 4] == 0 and obs["action_mask"][1, 4, 1] == 1
@@ -111,7 +111,7 @@ def pin_scenarios(make, kind="pin"):
     want = {0: [(0, 0), (0, 2)], 1: [(0, 3), (2, 3)], 2: [(3, 2), (3, 0)], 3: [(2, 0), (0, 0)]}
     for o, rel in want.items():
         env = make(mk(10, 10, 1, 1, 2, 4, 2, 4, 4, 2, 4, 4, 2, 2, "centroid", 2, 0.5))
-        env.reset(inst([(4, 3), (2, 2)], [(0, 0, 0, 0, 0), (0, 2, 0, 0, 1)], 1))
+        env.reset(instance=inst([(4, 3), (2, 2)], [(0, 0, 0, 0, 0), (0, 2, 0, 0, 1)], 1))
         obs, r, d, _ = env.step((o, 1, 2))
         f = obs["all_pins_num_feature"].reshape(-1, 4)
         rows = [0, 1] if kind == "spatial" else [0, 1]  # spatial: global ids 0, 1; pin: [comp 0, pin_id 0 / 1]
@@ -122,7 +122,7 @@ def pin_scenarios(make, kind="pin"):
         cfg = EnvConfig.pin(30, 30, 1, 1, 2, 5, 2, 5, 6, 1, 2, 4, 5, 2)
         env = make(cfg)
         pins = [(0, 0, 0, 0, 0), (2, 2, 0, 2, 1), (0, 2, 1, 0, 1), (3, 1, 1, 1, 0), (1, 0, 2, 1, 1), (2, 0, 2, 2, 0)]
-        obs = env.reset(inst([(1, 3), (4, 2), (5, 5)], pins, 3))
+        obs = env.reset(instance=inst([(1, 3), (4, 2), (5, 5)], pins, 3))
         assert not obs["all_pins_num_feature"][3:].any() and not obs["all_pins_cat_feature"][3:].any()
         obs, _, _, _ = env.step((0, 28, 26))
         n, c = obs["all_pins_num_feature"], obs["all_pins_cat_feature"]
@@ -138,7 +138,7 @@ def pin_scenarios(make, kind="pin"):
         assert not n[2, 2:].any()
         # test_env.py:626-658 test_step: placement_mask [2, 3, 0, 0], reward 0, not done, info {}
         env = make(EnvConfig.pin(6, 6, 1, 1, 2, 4, 2, 4, 4, 2, 4, 4, 2))
-        env.reset(inst([(2, 2), (3, 3)], [(0, 0, 0, 0, 0), (0, 1, 0, 1, 1)], 1))
+        env.reset(instance=inst([(2, 2), (3, 3)], [(0, 0, 0, 0, 0), (0, 1, 0, 1, 1)], 1))
         obs, r, d, info = env.step((0, 0, 0))
         assert obs["grid"][:2, :2].all() and list(obs["placement_mask"]) == [2, 3, 0, 0]
         assert list(obs["all_components_feature"][0]) == [2, 2, 0, 0, 4 / 36] and r == 0 and not d and info == {}
@@ -212,7 +212,7 @@ def reward_env_scenarios(make, reference_values=None):
     instance, placements = reward_instance("pin")
     for rt, wl, ni in (("beam", wl_beam, 1), ("centroid", wl_cen, 2), ("both", wl_beam, 1)):
         env = make(EnvConfig.pin(10, 10, 1, 1, 2, 4, 2, 4, 5, 2, 4, 4, 2, 2, rt, 2, 0.5))
-        env.reset(instance)
+        env.reset(instance=instance)
         for k, a in enumerate(placements):
             obs, r, d, info = env.step(a)
             assert d == (k == 4) and (r == 0.0 or k == 4), (rt, k)
@@ -223,7 +223,7 @@ def reward_env_scenarios(make, reference_values=None):
             got = (r, info["wirelength"], info["num_intersections"])
             assert np.array_equal(np.array(got).view(np.uint64), np.array(want).view(np.uint64)), (rt, got, want)
     env = make(EnvConfig.pin(10, 10, 1, 1, 2, 4, 2, 4, 5, 2, 4, 4, 2, 2, "both", 2, 0.5))
-    env.reset(instance)
+    env.reset(instance=instance)
     obs, r, d, info = env.step((0, 9, 9))                                             # :382-391: not all placed
     assert d and np.isclose(r, -0.5 * 2 * math.sqrt(2) - 0.5 * 24 / 8)
     assert info == {"wirelength": 0.5 * math.sqrt(200) * 8, "num_intersections": 24.0}  # the raw upper bounds (P:907-908)

@@ -114,7 +114,7 @@ def test_components_view_equals_the_reference_objects():
                 pre = f"{meta['name']}_s{seed}_e{ep}_"
                 ins = Instance(*(z[pre + k].astype(np.int64) if k != "num_nets" else int(z[pre + k]) for k in (
                     "comp_h", "comp_w", "num_nets", "pin_rel_x", "pin_rel_y", "pin_net", "pin_comp", "pin_id")))
-                env.reset(ins)
+                env.reset(instance=ins)
                 comps = env.components
                 for a in z[pre + "actions"]:
                     env.step(tuple(int(v) for v in a))

@@ -151,7 +151,7 @@ def test_episode_export_builds_reference_components():
     valid_actions = e.actions[:e.instance.num_components]
     comps, acts = io.episode_to_reference_objects(e.instance, valid_actions, Component, Pin)
     env = orc.OracleEnv(cfg)
-    env.reset(e.instance)
+    env.reset(instance=e.instance)
     for a in valid_actions:
         obs, _, _, _ = env.step(a)
     feats = obs["all_pins_num_feature"]

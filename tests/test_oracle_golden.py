@@ -22,7 +22,7 @@ def test_oracle_reproduces_reference_episode(name):
     meta, cfg, eps = load_case(name)
     for e in eps:
         env = orc.OracleEnv(cfg)
-        obs = env.reset(e.instance)
+        obs = env.reset(instance=e.instance)
         _check_obs(obs, e.obs, 0, cfg, (name, e.seed, e.ep, "reset"))
         for t, act in enumerate(e.actions):
             obs, r, d, info = env.step(act)

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define PCBENV_ABI_VERSION 2
+#define PCBENV_ABI_VERSION 3
 
 /* status codes (every function returning int) */
 #define PCBENV_OK 0
@@ -151,6 +151,20 @@ int64_t pcbenv_instance_stride(const pcbenv_config *cfg);
 int32_t pcbenv_max_total_pins(const pcbenv_config *cfg);
 
 int pcbenv_bind_buffers(pcbenv *env, const pcbenv_buffers *buffers);
+
+/* Tuning options of a handle (none changes a result; defaults are the measured choices of DESIGN.md).  They replace
+ * the environment variables earlier builds read: nothing in the library calls getenv. */
+enum pcbenv_option {
+    PCBENV_OPT_STREAM_THRESHOLD_BYTES = 1, /* cell-tensor bytes per launch above which observation stores bypass the
+                                              caches (`nt`); default 256 MiB = the Infinity Cache; 0 = always */
+    PCBENV_OPT_TERMINAL_TEAMS = 2,         /* workgroups of four-wavefront teams a one-transition launch reserves for the
+                                              environments that are certain to end their episode in it (k_step_mixed);
+                                              default num_envs / 8 for one-wavefront configurations, 0 = plain kernel */
+    PCBENV_OPT_GEN_GRID = 3,               /* workgroups of a refill launch of the on-device generator (default 2 048) */
+    PCBENV_OPT_GEN_LANES = 4               /* lanes per environment of the generator kernel: 0 = narrowest the
+                                              configuration allows, 32 / 64 force a wider group; before enabling it */
+};
+int pcbenv_set_option(pcbenv *env, int32_t option, int64_t value);
 
 /* Trajectory layout: every tensor of `buffers` is [num_slots, num_envs, ...] (C-contiguous) instead of
  * [num_envs, ...].  pcbenv_reset / pcbenv_step* write their outputs (observations, reward, done, info, marginals)

@@ -1,7 +1,5 @@
 // pcb_beam.h -- beam-search routes with the model of CPython's set iteration order
 // Part of libpcbenv.so's single translation unit (included by pcbenv_kernels.hip); CDNA4 / gfx950 only.
-#pragma once
-#include "pcb_reward.h"
 
 // ---- beam-search routing (S:1273-1286 pin_outlier, S:1303-1369 beam_search, S:1371-1406) -----------------
 // beam_search keeps, per popped path, the beam_width nearest unvisited points of
@@ -53,7 +51,7 @@ struct NetPts {  // coordinates packed one byte each into registers (<= 15 point
     }
 };
 
-__device__ inline u64 tuple_hash2(int x, int y) {  // Objects/tupleobject.c (xxHash-style), hash(int) == int
+static __device__ inline u64 tuple_hash2(int x, int y) {  // Objects/tupleobject.c (xxHash-style), hash(int) == int
     const u64 P1 = 11400714785074694791ull, P2 = 14029467366897019727ull, P5 = 2870177450012600261ull;
     u64 acc = P5;
     acc += (u64)(long long)x * P2; acc = (acc << 31) | (acc >> 33); acc *= P1;
@@ -61,12 +59,12 @@ __device__ inline u64 tuple_hash2(int x, int y) {  // Objects/tupleobject.c (xxH
     acc += 2ull ^ (P5 ^ 3527539ull);
     return acc == ~0ull ? 1546275796ull : acc;
 }
-__device__ inline void cs_init(CSet *s, int size) {
+static __device__ inline void cs_init(CSet *s, int size) {
     s->mask = size - 1; s->fill = 0; s->used = 0;
     for (int i = 0; i < 32; i++) s->t[i] = CS_EMPTY;
 }
 // first unused slot on the probe sequence of `hash` (set_insert_clean / the miss path of set_add_entry)
-__device__ inline int cs_probe_unused(const CSet *s, u64 hash, int *freeslot) {
+static __device__ inline int cs_probe_unused(const CSet *s, u64 hash, int *freeslot) {
     const unsigned mask = (unsigned)s->mask;
     u64 perturb = hash;
     unsigned i = (unsigned)hash & mask;
@@ -82,7 +80,7 @@ __device__ inline int cs_probe_unused(const CSet *s, u64 hash, int *freeslot) {
     }
 }
 // set_table_resize: re-insert the active keys in old slot order (the old table is copied to `tmp` first)
-__device__ inline void cs_resize(CSet *s, CSet *tmp, int minused, const NetPts &pt) {
+static __device__ inline void cs_resize(CSet *s, CSet *tmp, int minused, const NetPts &pt) {
     int newsize = 8;
     while (newsize <= minused) newsize <<= 1;
     *tmp = *s;
@@ -91,14 +89,14 @@ __device__ inline void cs_resize(CSet *s, CSet *tmp, int minused, const NetPts &
         if (tmp->t[i] < CS_DUMMY) s->t[cs_probe_unused(s, tuple_hash2(pt.x(tmp->t[i]), pt.y(tmp->t[i])), 0)] = tmp->t[i];
     s->fill = s->used = tmp->used;
 }
-__device__ inline void cs_add(CSet *s, CSet *tmp, int key, const NetPts &pt) {
+static __device__ inline void cs_add(CSet *s, CSet *tmp, int key, const NetPts &pt) {
     int freeslot = -1;
     const int slot = cs_probe_unused(s, tuple_hash2(pt.x(key), pt.y(key)), &freeslot);
     if (freeslot >= 0) { s->t[freeslot] = (unsigned char)key; s->used++; return; }
     s->t[slot] = (unsigned char)key; s->fill++; s->used++;
     if (s->fill * 5 >= s->mask * 3) cs_resize(s, tmp, s->used * 4, pt);
 }
-__device__ inline void cs_discard(CSet *s, int key, const NetPts &pt) {
+static __device__ inline void cs_discard(CSet *s, int key, const NetPts &pt) {
     const unsigned mask = (unsigned)s->mask;
     const u64 hash = tuple_hash2(pt.x(key), pt.y(key));
     u64 perturb = hash;
@@ -116,7 +114,7 @@ __device__ inline void cs_discard(CSet *s, int key, const NetPts &pt) {
 }
 // Iteration order of `set(points) - visited` (set_difference: copy-and-discard when len(A) >> 2 > len(visited),
 // else a fresh set filled in A's slot order).  A and R are LDS tables; `order` receives point indices.
-__device__ inline int cs_difference_order(CSet *A, CSet *R, int m, unsigned visited, const NetPts &pt, unsigned char *order) {
+static __device__ inline int cs_difference_order(CSet *A, CSet *R, int m, unsigned visited, const NetPts &pt, unsigned char *order) {
     // points_to_visit = set(points): inserted in list order.  R doubles as the resize temporary while A is built.
     cs_init(A, 8);
     for (int i = 0; i < m; i++) cs_add(A, R, i, pt);
@@ -149,7 +147,7 @@ __device__ inline int cs_difference_order(CSet *A, CSet *R, int m, unsigned visi
 // `A = set(points)` and the tuple hashes depend on the net only: built once per net (first tie) and kept in LDS.
 // (Low 32 bits of each hash: they carry the first five perturb steps of an 8-slot walk; a longer walk -- occupied slots
 // can be revisited -- recomputes the full hash.)
-__device__ inline void cs_build_points(CSet *A, CSet *tmp, unsigned *hs, int m, const NetPts &pt) {
+static __device__ inline void cs_build_points(CSet *A, CSet *tmp, unsigned *hs, int m, const NetPts &pt) {
     cs_init(A, 8);
     for (int i = 0; i < m; i++) { hs[i] = (unsigned)tuple_hash2(pt.x(i), pt.y(i)); cs_add(A, tmp, i, pt); }
 }
@@ -157,7 +155,7 @@ __device__ inline void cs_build_points(CSet *A, CSet *tmp, unsigned *hs, int m, 
 // A's slot order" branch of set_difference: the result table keeps its 8 slots (no resize before the 5th insert), so
 // it lives in one 64-bit register, one byte per slot (mask 7: LINEAR_PROBES never applies, only the perturb walk).
 // Returns the number of elements, their point indices in iteration order packed one per byte.
-__device__ inline int cs_small_difference_order(const CSet *A, const unsigned *hs, unsigned visited, const NetPts &pt, unsigned *packed) {
+static __device__ inline int cs_small_difference_order(const CSet *A, const unsigned *hs, unsigned visited, const NetPts &pt, unsigned *packed) {
     const unsigned *tw = (const unsigned *)A->t;  // 4-byte aligned (offset 12 of a 16-byte aligned record)
     const int nw = (A->mask + 1) >> 2;            // 2 or 8 words
     unsigned w[8];
@@ -215,7 +213,7 @@ __device__ inline int cs_small_difference_order(const CSet *A, const unsigned *h
 #define BEAM_T0() do { } while (0)
 #define BEAM_ACC(k) do { } while (0)
 #endif
-__device__ inline void wave_lds_order() {  // LDS traffic of one wavefront executes in order: only the compiler must not reorder
+static __device__ inline void wave_lds_order() {  // LDS traffic of one wavefront executes in order: only the compiler must not reorder
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
@@ -237,7 +235,7 @@ template <int MAXC> struct NetAll {
     }
 };
 // python's list comparison of two queued paths of equal priority (entries hold pin indices; all paths of a queue have one length)
-template <int MAXC> __device__ inline bool path_less(const BsEntry &a, const BsEntry &e, const NetAll<MAXC> &pt) {
+template <int MAXC> static __device__ inline bool path_less(const BsEntry &a, const BsEntry &e, const NetAll<MAXC> &pt) {
     bool less = a.len() < e.len();
     const int n = a.len() < e.len() ? a.len() : e.len();
     for (int j = 0; j < n; j++) {
@@ -250,7 +248,7 @@ template <int MAXC> __device__ inline bool path_less(const BsEntry &a, const BsE
 }
 // SMALL: nets of <= 8 pins and beam widths <= 2 (queue <= 4 entries): everything unrolled in registers
 template <bool SMALL>
-__device__ __forceinline__ void beam_route_lanes(const SegView &v, const PinRec *pins, int s, int cnt, int st, int k, unsigned char *scratch, int t, unsigned long long *beam_dbg) {
+static __device__ __forceinline__ void beam_route_lanes(const SegView &v, const PinRec *pins, int s, int cnt, int st, int k, unsigned char *scratch, int t, unsigned long long *beam_dbg) {
     constexpr int MAXC = SMALL ? 8 : PCBENV_MAX_PINS_PER_NET, MAXQ = SMALL ? 4 : PCBENV_MAX_BEAM_WIDTH * PCBENV_MAX_BEAM_WIDTH;
     constexpr unsigned KINF = 0x7FFFFFFFu;
     BEAM_T0();
@@ -447,7 +445,7 @@ __device__ __forceinline__ void beam_route_lanes(const SegView &v, const PinRec 
     wave_lds_order();
 }
 template <bool SMALL>
-__device__ __forceinline__ void beam_routes_lanes(const SegView &v, const PinRec *pins, int nn, int k, unsigned char *beam, int lane, unsigned long long *beam_dbg) {
+static __device__ __forceinline__ void beam_routes_lanes(const SegView &v, const PinRec *pins, int nn, int k, unsigned char *beam, int lane, unsigned long long *beam_dbg) {
     const int groups = NT / BEAM_LANES_PER_NET, gi = lane / BEAM_LANES_PER_NET, t = lane & (BEAM_LANES_PER_NET - 1);
     for (int n0 = 0; n0 < nn; n0 += groups) {
         const int n = n0 + gi;
@@ -468,7 +466,7 @@ __device__ __forceinline__ void beam_routes_lanes(const SegView &v, const PinRec
     }
 }
 // all nets of the environment: v.D / v.act / segment slots are filled with the beam routes
-__device__ __forceinline__ void beam_routes(const SegView &v, const EnvHdr *hdr, const PinRec *pins, int k, unsigned char *beam, int lane, unsigned long long *beam_dbg) {
+static __device__ __forceinline__ void beam_routes(const SegView &v, const EnvHdr *hdr, const PinRec *pins, int k, unsigned char *beam, int lane, unsigned long long *beam_dbg) {
     const int np = hdr->npins, nn = hdr->nnets;
     for (int q = lane; q < np; q += NT) {  // distance of every pin to its net's centroid (v.D is free until the segments are written)
         const PinRec pr = pins[q];
@@ -495,9 +493,11 @@ __device__ __forceinline__ void beam_routes(const SegView &v, const EnvHdr *hdr,
     }
 }
 
-// beam (and, for "both", centroid) routes of the terminal state -> wirelength, #intersections of the chosen route
-__device__ __forceinline__ void route_beam_or_both(const DevParams &p, const EnvHdr *hdr, const PinRec *pins, double *seg,
-                                          int lane, double *wirelength, int *nintersections) {
+// beam (and, for "both", centroid) routes of the terminal state -> wirelength and this team's share of the #intersections
+// of the beam route (wl[0], ni[0]) and, reward_type "both", of the centroid route (wl[1], ni[1]); the caller picks
+// (S:609-627 lowest_num_intersections) once the shares of all teams are in.
+static __device__ __forceinline__ void route_beam_or_both(const DevParams &p, const EnvHdr *hdr, const PinRec *pins, double *seg,
+                                          int lane, int part, int nparts, double *wl, int *ni) {
     const SegView v = seg_view(seg, p.P);
     unsigned char *beam = v.beam;
     net_offsets_and_centroids(v, hdr, pins, lane);
@@ -506,14 +506,11 @@ __device__ __forceinline__ void route_beam_or_both(const DevParams &p, const Env
     beam_routes(v, hdr, pins, p.beam_width, beam, lane, p.dbg);
     lds_sync();
     STAMP(24);
-    count_and_length(p, v, hdr, pins, lane, wirelength, nintersections);
+    count_and_length(p, v, hdr, pins, lane, part, nparts, &wl[0], &ni[0]);
     STAMP(25);
-    if (p.reward_type == PCBENV_REWARD_BOTH) {  // S:609-627 lowest_num_intersections: ties keep the beam route
-        double wc; int kc;
+    if (p.reward_type == PCBENV_REWARD_BOTH) {
         build_centroid_segments(v, hdr, pins, lane);
-        count_and_length(p, v, hdr, pins, lane, &wc, &kc);
-        if (kc < *nintersections) { *nintersections = kc; *wirelength = wc; }
+        count_and_length(p, v, hdr, pins, lane, part, nparts, &wl[1], &ni[1]);
     }
     STAMP(8);
 }
-

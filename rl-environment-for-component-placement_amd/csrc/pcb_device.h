@@ -12,9 +12,11 @@
 typedef unsigned long long u64;
 
 #define WAVE 64
-#define NT ((int)blockDim.x)   // threads per environment: 64 (one wave) or 256 (four waves, large grids)
 #define MAX_NT 256
 #define HDR_BYTES 64
+#define TERM_CNT_STRIDE 32u  // unsigned words between the shard counters of the terminal list: one 128-byte line each
+#define TERM_SHARD_BITS 4
+#define TERM_SHARDS (1u << TERM_SHARD_BITS)
 
 // ----------------------------------------------------------------------------------------------
 // device-side parameter block (kernel argument, by value)
@@ -44,6 +46,19 @@ struct DevParams {
     // in the state block is written back lazily and only ever re-read on the environment's own XCD; a kernel on
     // another stream (k_gen_fill) may run on any XCD, whose L2 is not coherent with the writer's.
     unsigned *cursor_pub;
+    // Terminal list (Team<>::run_env has the story): `seq` numbers the step launches of this handle; launch seq starts
+    // term_hpe helper teams per entry of ring seq & 3 (term_wgs = term_cap entries' worth of workgroups behind the
+    // environments' own, when the launch has helpers at all), appends to ring (seq + 1) & 3 and clears the counters of ring
+    // (seq + 2) & 3.  A ring is TERM_SHARDS shards of term_cap / TERM_SHARDS entries, each with a counter on a line of its
+    // own (term_cnt[(ring * TERM_SHARDS + shard) * TERM_CNT_STRIDE]); entry (shard, idx) sits at shard * cps + idx.
+    // term_cap == 0: no lists are kept; term_wgs == 0: this launch has no helpers (marks are ignored).
+    unsigned seq;
+    int term_wgs, term_cap, term_hpe;
+    int *term_list;
+    unsigned *term_cnt;
+    u64 *term_mark;    // [2][B]: (launch number << 32 | list position) of environment e for launches of that parity
+    u64 *term_arrive;  // [term_cap]: where the shares of a routing reward meet (terminal_reward)
+    unsigned char *state_out;  // the state blocks this launch writes (p.state: the ones it reads); equal for in-place kernels
 };
 // Loads of data another stream's kernel (or a DMA) has written since this XCD last read the same addresses: instance
 // records and the generator's counters.  Agent-scope loads (`sc1`) are served coherently; a plain load may hit a
@@ -55,13 +70,15 @@ __device__ inline void store_agent(unsigned *p, unsigned v) { __hip_atomic_store
 // In-kernel stamps (cdna_hip_programming.md §7): only in a separate diagnostic build, written to a buffer nothing
 // else reads; `PCBENV_STAMPS=1` in the environment allocates it, tools/kernel_stamps.py prints the phase profile.
 #ifdef PCBENV_STAMPS
-#define STAMP(k) do { if (threadIdx.x == 0 && p.dbg) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); p.dbg[(size_t)blockIdx.x * 32 + (k)] = t_; } } while (0)
-#define STAMP_RT(k) do { if (threadIdx.x == 0 && p.dbg) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); p.dbg[(size_t)blockIdx.x * 32 + (k)] = t_; } } while (0)
+#define STAMP(k) do { if ((threadIdx.x & (NT - 1)) == 0 && p.dbg) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); p.dbg[(size_t)blockIdx.x * 32 + (k)] = t_; } } while (0)
+#define STAMP_RT(k) do { if ((threadIdx.x & (NT - 1)) == 0 && p.dbg) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); p.dbg[(size_t)blockIdx.x * 32 + (k)] = t_; } } while (0)
 // accumulate elapsed shader cycles of a region / an arbitrary value into slot k (the kernel's first STAMP must zero it)
 #define STAMP_T0() unsigned long long st0_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st0_) :: "memory")
-#define STAMP_ACC_SINCE(k, dep) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : "v"(dep) : "memory"); if (threadIdx.x == 0 && p.dbg) p.dbg[(size_t)blockIdx.x * 32 + (k)] += t_ - st0_; } while (0)
-#define STAMP_ADD(k, v) do { if (threadIdx.x == 0 && p.dbg) p.dbg[(size_t)blockIdx.x * 32 + (k)] += (unsigned long long)(v); } while (0)
-#define STAMP_ZERO(k) do { if (threadIdx.x == 0 && p.dbg) p.dbg[(size_t)blockIdx.x * 32 + (k)] = 0ull; } while (0)
+#define STAMP_ACC_SINCE(k, dep) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : "v"(dep) : "memory"); if ((threadIdx.x & (NT - 1)) == 0 && p.dbg) p.dbg[(size_t)blockIdx.x * 32 + (k)] += t_ - st0_; } while (0)
+#define STAMP_ADD(k, v) do { if ((threadIdx.x & (NT - 1)) == 0 && p.dbg) p.dbg[(size_t)blockIdx.x * 32 + (k)] += (unsigned long long)(v); } while (0)
+#define STAMP_ZERO(k) do { if ((threadIdx.x & (NT - 1)) == 0 && p.dbg) p.dbg[(size_t)blockIdx.x * 32 + (k)] = 0ull; } while (0)
+// the stamps above index their rows by blockIdx.x: shift the table so that this team's rows are environment e's
+#define STAMP_ROWS_BY_ENV(launch, e) DevParams p = (launch); if (p.dbg) p.dbg += ((long long)(e) - (long long)blockIdx.x) * 32
 #else
 #define STAMP(k) do { } while (0)
 #define STAMP_RT(k) do { } while (0)
@@ -69,6 +86,7 @@ __device__ inline void store_agent(unsigned *p, unsigned v) { __hip_atomic_store
 #define STAMP_ACC_SINCE(k, dep) do { } while (0)
 #define STAMP_ADD(k, v) do { } while (0)
 #define STAMP_ZERO(k) do { } while (0)
+#define STAMP_ROWS_BY_ENV(launch, e) const DevParams &p = (launch)
 #endif
 
 // per-environment header at the start of a state block
@@ -95,27 +113,6 @@ struct CompRec { unsigned char h, w; signed char px, py; unsigned char o, pad[3]
 struct PinRec { unsigned char rel_x, rel_y; signed char abs_x, abs_y; unsigned char net, comp; unsigned short id; };
 #define PIN_ID_MASK 0x7FFF
 #define PIN_LOSER 0x8000  // pin env quirk Q1: a later pin of the same component shares this feature row
-
-// Workgroup barrier that waits for LDS traffic only.  __syncthreads() also drains the global stores in flight
-// (s_waitcnt vmcnt(0)), which would serialise the observation write stream between kernel phases.
-__device__ inline void lds_sync() {
-#ifdef PCBENV_FULL_SYNC
-    __syncthreads();
-    return;
-#endif
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
-// any() over the workgroup; `flag` is an LDS word
-__device__ inline bool block_any(bool v, unsigned *flag) {
-    if (NT == WAVE) return __any(v);
-    if (threadIdx.x == 0) *flag = 0;
-    lds_sync();
-    if (__any(v) && (threadIdx.x & 63) == 0) *flag = 1;
-    lds_sync();
-    return *flag != 0;
-}
 
 // ----------------------------------------------------------------------------------------------
 // bit rows
@@ -202,102 +199,13 @@ __device__ inline uint4 expand16(unsigned bits) {
     return make_uint4(expand4(bits & 15u), expand4((bits >> 4) & 15u), expand4((bits >> 8) & 15u), expand4((bits >> 12) & 15u));
 }
 
-// Write one H x W uint8 plane (0/1) from bit rows in LDS: 16 bytes per lane, 1 KiB per wave instruction.
-// Rows [r0, r1) only (full plane: 0, H).
-template <int WW, bool STREAM> __device__ inline void emit_plane_(unsigned char *dst, const u64 *bits, int r0, int r1, int W, int lane) {
-    if ((W & 15) == 0 && (((uintptr_t)dst) & 15) == 0) {
-        const ObsDst d = obs_dst(dst, (long long)r1 * W);
-        const int sh = (W & (W - 1)) == 0 ? __ffs(W) - 1 : -1;
-        for (int c = r0 * W / 16 + lane; c < r1 * W / 16; c += NT) {
-            int cell = c * 16, r = sh >= 0 ? cell >> sh : cell / W, col = cell - r * W;
-            unsigned b = (unsigned)(bits[r * WW + (col >> 6)] >> (col & 63)) & 0xFFFFu;
-            STORE16<STREAM>(d, (unsigned)cell, expand16(b));
-        }
-    } else {  // odd widths (the reference's small test grids): byte path
-        for (int i = r0 * W + lane; i < r1 * W; i += NT) {
-            int r = i / W, col = i - r * W;
-            dst[i] = (unsigned char)((bits[r * WW + (col >> 6)] >> (col & 63)) & 1ull);
-        }
-    }
-}
-template <bool STREAM> __device__ inline void emit_zero_(unsigned char *dst, long long bytes, int lane) {
-    if ((bytes & 15) == 0 && (((uintptr_t)dst) & 15) == 0) {
-        const ObsDst d = obs_dst(dst, bytes);
-        for (int c = lane; c < (int)(bytes / 16); c += NT) STORE16<STREAM>(d, (unsigned)c * 16u, make_uint4(0, 0, 0, 0));
-    } else {
-        for (long long i = lane; i < bytes; i += NT) dst[i] = 0;
-    }
-}
 __device__ inline void STORE16_dyn(const ObsDst &d, unsigned off, uint4 v, bool stream) { if (stream) STORE16<true>(d, off, v); else STORE16<false>(d, off, v); }
-// The same plane to two destinations (action_mask[o] and action_mask[o + 2] of the pin environments are equal,
-// S:1852-1853): the bits are read and expanded once, stored twice.
-template <int WW, bool STREAM> __device__ inline void emit_plane2_(unsigned char *dst, unsigned char *dst2, const u64 *bits, int H, int W, int lane) {
-    if ((W & 15) == 0 && (((uintptr_t)dst) & 15) == 0 && (((uintptr_t)dst2) & 15) == 0) {
-        const ObsDst d = obs_dst(dst, (long long)H * W), d2 = obs_dst(dst2, (long long)H * W);
-        const int sh = (W & (W - 1)) == 0 ? __ffs(W) - 1 : -1;
-        for (int c = lane; c < H * W / 16; c += NT) {
-            int cell = c * 16, r = sh >= 0 ? cell >> sh : cell / W, col = cell - r * W;
-            unsigned b = (unsigned)(bits[r * WW + (col >> 6)] >> (col & 63)) & 0xFFFFu;
-            const uint4 v = expand16(b);
-            STORE16<STREAM>(d, (unsigned)cell, v);
-            STORE16<STREAM>(d2, (unsigned)cell, v);
-        }
-    } else {
-        emit_plane_<WW, STREAM>(dst, bits, 0, H, W, lane);
-        emit_plane_<WW, STREAM>(dst2, bits, 0, H, W, lane);
-    }
-}
-// the policy is chosen once per plane (wave-uniform branch), not per store
-template <int WW> __device__ inline void emit_plane(unsigned char *dst, const u64 *bits, int r0, int r1, int W, int lane, bool stream) {
-    if (stream) emit_plane_<WW, true>(dst, bits, r0, r1, W, lane); else emit_plane_<WW, false>(dst, bits, r0, r1, W, lane);
-}
-template <int WW> __device__ inline void emit_plane2(unsigned char *dst, unsigned char *dst2, const u64 *bits, int H, int W, int lane, bool stream) {
-    if (stream) emit_plane2_<WW, true>(dst, dst2, bits, H, W, lane); else emit_plane2_<WW, false>(dst, dst2, bits, H, W, lane);
-}
-__device__ inline void emit_zero(unsigned char *dst, long long bytes, int lane, bool stream) {
-    if (stream) emit_zero_<true>(dst, bytes, lane); else emit_zero_<false>(dst, bytes, lane);
-}
-
-// Legal-placement bit mask for a ph x pw window (R:526-567, S:1792-1835):
-// vm[r] bit j = 1 iff r <= H-ph and j <= W-pw and occ[r..r+ph-1][j..j+pw-1] is empty.
-// Returns (wave-uniform) whether any bit is set.
 // value of `a` held by lane + s (0 beyond the wavefront): one cross-lane read per 32-bit half
 __device__ inline u64 lane_down(u64 a, int s, int lane) {
     const int src = (lane + s) << 2;
     const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned)a), hi = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned)(a >> 32));
     return lane + s < WAVE ? (((u64)hi << 32) | lo) : 0ull;
 }
-template <int WW>
-__device__ inline bool window_mask(const u64 *occ, u64 *hf, u64 *vm, int H, int W, int ph, int pw, int lane, unsigned *flag) {
-#ifndef PCBENV_FOLD_LDS
-    if (WW == 1 && NT == WAVE && H <= WAVE) {
-        // One row per lane: the vertical OR over ph rows by log-step doubling across lanes, like the horizontal one across
-        // bits -- no staging of the folded rows in LDS, no barrier, at most three cross-lane steps for ph <= 8.
-        u64 a = lane < H ? hfold<1>(Row<1>::load(occ + lane), pw).a : 0ull;
-        int s = 1;
-        while (2 * s <= ph) { a |= lane_down(a, s, lane); s *= 2; }
-        if (s < ph) a |= lane_down(a, ph - s, lane);
-        const u64 v = (lane + ph <= H) ? Row<1>{a}.free_below(W - pw + 1).a : 0ull;
-        if (lane < H) vm[lane] = v;
-        return __any(v != 0ull);
-    }
-#endif
-    for (int r = lane; r < H; r += NT) hfold<WW>(Row<WW>::load(occ + r * WW), pw).store(hf + r * WW);
-    lds_sync();
-    bool any = false;
-    for (int r = lane; r < H; r += NT) {
-        Row<WW> v = Row<WW>::zero();
-        if (r + ph <= H) {
-            Row<WW> acc = Row<WW>::load(hf + r * WW);
-            for (int k = 1; k < ph; k++) acc = acc | Row<WW>::load(hf + (r + k) * WW);
-            v = acc.free_below(W - pw + 1);
-        }
-        v.store(vm + r * WW);
-        any |= v.any();
-    }
-    return block_any(any, flag);
-}
-
 // Inclusive prefix sum over the 64 lanes with DPP row shifts / row broadcasts (no LDS round trips).
 __device__ inline int wave_inclusive_scan(int x, int lane) {
     const int row = lane & 15;

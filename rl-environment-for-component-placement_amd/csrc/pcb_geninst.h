@@ -557,10 +557,10 @@ __global__ __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(WAVE) vo
 // Measured on c3 (bench.py fresh-instance leg, 4 096 environments, same box): G = 64: 126 M env-steps/s, G = 32: 145 M,
 // G = 16: 156 M (replayed queue: 200 M).  Packing pays although a cross-lane read is a ds_bpermute round trip at G < 64
 // instead of a v_readlane: with the multinomial chains tabulated, the dependent chain of a record is short enough.
-// PCBENV_GEN_LANES = 16 / 32 / 64 forces a wider group (experiments, tests).
-static inline int gen_group_lanes(int C, int N, int P) {
+// `forced` = 32 / 64 (PCBENV_OPT_GEN_LANES) selects a wider group than the narrowest possible (experiments, tests).
+static inline int gen_group_lanes(int C, int N, int P, int forced = 0) {
     int g = (C <= 16 && N <= 16 && P <= 64) ? 16 : (C <= 32 && N <= 32 && P <= 128) ? 32 : 64;
-    if (const char *ev = getenv("PCBENV_GEN_LANES")) { const int f = atoi(ev); if ((f == 32 || f == 64) && f > g) g = f; }
+    if ((forced == 32 || forced == 64) && forced > g) g = forced;
     return g;
 }
 #define GEN_LDS_BYTES(instStride, G) ((WAVE / (G)) * ((GEN_GROUP_LDS_BYTES(instStride) + 15) & ~15))

@@ -1,7 +1,5 @@
 // pcb_observe.h -- state block staging through LDS, legal-mask fold + observation emission, pin_grid, feature rows, terminal reward
 // Part of libpcbenv.so's single translation unit (included by pcbenv_kernels.hip); CDNA4 / gfx950 only.
-#pragma once
-#include "pcb_beam.h"
 
 // ----------------------------------------------------------------------------------------------
 // shared pieces of reset / step
@@ -11,8 +9,8 @@ struct Lds {
     u64 *hf; unsigned char *cls; double *seg;
 };
 // Row of environment e in the [num_slots, B, ...] output tensors for the slot a step writes (DevParams::slot).
-__device__ inline int out_row(const DevParams &p, int slot, int e) { return slot * p.B + e; }
-__device__ inline Lds carve(unsigned char *smem, const DevParams &p) {
+static __device__ inline int out_row(const DevParams &p, int slot, int e) { return slot * p.B + e; }
+static __device__ inline Lds carve(unsigned char *smem, const DevParams &p) {
     Lds l;
     l.hdr = (EnvHdr *)smem;
     l.occ = (u64 *)(smem + p.offOcc);
@@ -25,7 +23,7 @@ __device__ inline Lds carve(unsigned char *smem, const DevParams &p) {
     l.seg = (double *)(smem + p.ldsSeg);
     return l;
 }
-__device__ inline void load_state(unsigned char *smem, const DevParams &p, int e, int lane) {
+static __device__ inline void load_state(unsigned char *smem, const DevParams &p, int e, int lane) {
     const uint4 *src = (const uint4 *)(p.state + (size_t)e * p.stateStride);
     uint4 *dst = (uint4 *)smem;
     const int n = (int)(p.stateStride / 16);
@@ -44,9 +42,9 @@ __device__ inline void load_state(unsigned char *smem, const DevParams &p, int e
     }
     lds_sync();
 }
-__device__ inline void store_state(const unsigned char *smem, const DevParams &p, int e, int lane) {
+static __device__ inline void store_state(const unsigned char *smem, const DevParams &p, int e, int lane) {
     lds_sync();
-    uint4 *dst = (uint4 *)(p.state + (size_t)e * p.stateStride);
+    uint4 *dst = (uint4 *)(p.state_out + (size_t)e * p.stateStride);
     const uint4 *src = (const uint4 *)smem;
     // plain write-back stores: environment e runs on XCD e % 8 in every launch, so its state block is an L2 hit next step
     for (int i = lane; i < (int)(p.stateStride / 16); i += NT) dst[i] = src[i];
@@ -54,7 +52,7 @@ __device__ inline void store_state(const unsigned char *smem, const DevParams &p
 
 // Marginals of the legal mask for factorised policies (factorized_action_distributions.py:358, :401): per
 // orientation "any legal cell" and per (orientation, row) "any legal column", read off the bit rows in LDS.
-template <int KIND, int WW> __device__ inline void emit_marginals(const DevParams &p, Lds &l, int row, int lane) {
+template <int KIND, int WW> static __device__ inline void emit_marginals(const DevParams &p, Lds &l, int row, int lane) {
     if (!p.buf.mask_rows && !p.buf.mask_orientation) return;
     const int H = p.H, plane = H * WW, O = p.O;
     for (int i = lane; i < O * H; i += NT) {
@@ -78,7 +76,7 @@ template <int KIND, int WW> __device__ inline void emit_marginals(const DevParam
 // [gr0, gr1) and the action_mask planes, each written as soon as its bits exist so that the HBM write stream
 // starts before the second orientation is folded.  Returns "some action is legal".
 template <int KIND, int WW>
-__device__ inline bool mask_and_emit(const DevParams &p, Lds &l, int row, int lane, bool emit, int gr0, int gr1) {
+static __device__ inline bool mask_and_emit(const DevParams &p, Lds &l, int row, int lane, bool emit, int gr0, int gr1) {
     const int H = p.H, W = p.W, HW = H * W, plane = H * WW;
     const int cur = l.hdr->cur;
     unsigned char *m = (emit && p.buf.action_mask) ? p.buf.action_mask + (size_t)row * p.O * HW : 0;
@@ -113,7 +111,7 @@ __device__ inline bool mask_and_emit(const DevParams &p, Lds &l, int row, int la
 
 // S:1663-1675 draw_pins: class map (0 empty, 1 occupied without pin, n+2 pin of net n) -> one-hot[:, :, 1:];
 // rows [r0, r1) of the (H, W, K) tensor (a step only changes the rows of the placed rectangle).
-template <int WW> __device__ inline void emit_pin_grid(const DevParams &p, Lds &l, int row, int lane, int r0, int r1) {
+template <int WW> static __device__ inline void emit_pin_grid(const DevParams &p, Lds &l, int row, int lane, int r0, int r1) {
     if (!p.buf.pin_grid) return;
     const int W = p.W, HW = p.H * W, K = p.K;
     const int c0 = r0 * W, c1 = r1 * W;
@@ -182,7 +180,7 @@ template <int WW> __device__ inline void emit_pin_grid(const DevParams &p, Lds &
 }
 
 // Feature rows of one pin (P:72-103 / S:70-104 Pin.calculate_feature): [rel_x, rel_y, abs_x, abs_y]
-template <int KIND> __device__ inline void write_pin_num(const DevParams &p, int row_, const PinRec &pr) {
+template <int KIND> static __device__ inline void write_pin_num(const DevParams &p, int row_, const PinRec &pr) {
     if (!p.buf.all_pins_num_feature) return;
     int row;
     if (KIND == PCBENV_SPATIAL) row = pr.id & PIN_ID_MASK;
@@ -198,13 +196,13 @@ template <int KIND> __device__ inline void write_pin_num(const DevParams &p, int
 // shows the in-place rotation of place_component (quirk Q4): for a placed component the rotation is undone here
 // with the orientation kept in its record.
 struct PinTables { unsigned short *pid; unsigned *netmask; };
-__device__ inline PinTables pin_tables(const DevParams &p, Lds &l) {
+static __device__ inline PinTables pin_tables(const DevParams &p, Lds &l) {
     PinTables t;
     t.pid = (unsigned short *)l.cls;
     t.netmask = (unsigned *)(l.cls + ((p.C * p.mp * 2 + 3) & ~3));
     return t;
 }
-__device__ inline void build_pin_tables(const DevParams &p, Lds &l, int lane) {
+static __device__ inline void build_pin_tables(const DevParams &p, Lds &l, int lane) {
     const PinTables t = pin_tables(p, l);
     const int np = l.hdr->npins;
     lds_sync();
@@ -227,7 +225,7 @@ __device__ inline void build_pin_tables(const DevParams &p, Lds &l, int lane) {
 }
 // S:1677-1697 draw_components from the tables above: byte (cell, ch) = ch == 0 ? component exists : net ch-1 has a
 // pin on the cell; each byte written once.
-__device__ inline void emit_component_grid(const DevParams &p, Lds &l, int row, int lane) {
+static __device__ inline void emit_component_grid(const DevParams &p, Lds &l, int row, int lane) {
     if (!p.buf.component_grid) return;
     const PinTables t = pin_tables(p, l);
     const int nc = l.hdr->ncomp;
@@ -261,7 +259,7 @@ __device__ inline void emit_component_grid(const DevParams &p, Lds &l, int row, 
 // the trajectory layout (num_slots > 1), where every step lands in a fresh slot.  all_components_feature
 // (R:60-79, S:203-239), placement / component masks (S:1445-1451, :1592-1602; R:275-298), pin features
 // (P:72-103 / S:70-104, quirk Q1 for the pin env, S:1520 last row).  Spatial: build_pin_tables() must have run.
-template <int KIND> __device__ inline void emit_features_full(const DevParams &p, Lds &l, int row, int lane) {
+template <int KIND> static __device__ inline void emit_features_full(const DevParams &p, Lds &l, int row, int lane) {
     if (KIND == PCBENV_SQUARE) return;
     const int nc = l.hdr->ncomp, np = l.hdr->npins, cur = l.hdr->cur;
     if (p.buf.all_components_feature) {
@@ -335,7 +333,7 @@ template <int KIND> __device__ inline void emit_features_full(const DevParams &p
         } else {  // more rows than the bit map holds (tiny grids with large components): zero everything, then the rows
             for (int i = lane; i < p.pinRows * 4; i += NT) if (fn) fn[i] = 0.0;
             for (int i = lane; i < p.pinRows; i += NT) if (fc) fc[i] = 0.0;
-            __syncthreads();
+            store_drain_sync();
             for (int q = lane; q < np; q += NT) {
                 const PinRec pr = l.pins[q];
                 if (pr.id & PIN_LOSER) continue;
@@ -349,19 +347,35 @@ template <int KIND> __device__ inline void emit_features_full(const DevParams &p
 
 // Terminal reward (S:793-929 find_reward), all three reward types, inside the step kernel.
 // ROUTES = false compiles the beam-search code out (reward_type centroid: what every shipped reference config uses).
+// nparts > 1: this team is one of `nparts` (the environment's own wavefront = part 0 and its reward helpers, run_env)
+// that each count a share of the segment pairs: the shares meet in term_arrive[pos] -- one returning 64-bit atomic add
+// of (1 arrival | share of the first route's count << 8 | share of the second's << 36) -- and the team whose add comes
+// last has the totals, writes reward and info, and clears the word for the next launch.  Everything else (routes,
+// wirelength: a sequential float64 sum) every team computes for itself, so the result does not depend on who is last.
 template <int KIND, bool ROUTES>
-__device__ __forceinline__ void terminal_reward(const DevParams &p, Lds &l, int row, int lane) {
+static __device__ __forceinline__ void terminal_reward(const DevParams &p, Lds &l, int row, int lane, int part, int nparts, unsigned pos) {
     const bool placed_all = l.hdr->cur < 0;
     double reward, wl, ni;
     if (!placed_all) {  // S:853-863 worst case: the upper bounds, normalised (spatial: twice, quirk Q3)
         reward = -p.w_wl * (p.max_wl / p.wl_norm) - p.w_int * (p.max_int / p.int_norm);
         wl = p.max_wl; ni = p.max_int;
     } else {
-        double wsum; int cnt;
-        if (!ROUTES) route_centroid(p, l.hdr, l.pins, l.seg, lane, &wsum, &cnt);
-        else route_beam_or_both(p, l.hdr, l.pins, l.seg, lane, &wsum, &cnt);
-        wl = wsum / p.wl_norm;
-        ni = (double)cnt / p.int_norm;
+        double wsum[2] = {0.0, 0.0}; int cnt[2] = {0, 0};
+        if (!ROUTES) route_centroid(p, l.hdr, l.pins, l.seg, lane, part, nparts, &wsum[0], &cnt[0]);
+        else route_beam_or_both(p, l.hdr, l.pins, l.seg, lane, part, nparts, wsum, cnt);
+        if (nparts > 1) {
+            if (lane != 0) return;  // one lane carries the shares; nobody else writes anything below
+            const u64 mine = 1ull | ((u64)(unsigned)cnt[0] << 8) | ((u64)(unsigned)cnt[1] << 36);
+            const u64 before = atomicAdd((unsigned long long *)(p.term_arrive + pos), (unsigned long long)mine);
+            if ((int)(before & 0xFFull) != nparts - 1) return;  // not the last: the totals are somebody else's to write
+            const u64 total = before + mine;
+            cnt[0] = (int)((total >> 8) & 0xFFFFFFFull); cnt[1] = (int)(total >> 36);
+            __hip_atomic_store(p.term_arrive + pos, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // S:609-627 lowest_num_intersections: ties keep the beam route (quirk Q9)
+        const int pick = (ROUTES && p.reward_type == PCBENV_REWARD_BOTH && cnt[1] < cnt[0]) ? 1 : 0;
+        wl = wsum[pick] / p.wl_norm;
+        ni = (double)cnt[pick] / p.int_norm;
         reward = -1 * (p.w_wl * wl + p.w_int * ni);
     }
     if (lane == 0) {
@@ -369,4 +383,3 @@ __device__ __forceinline__ void terminal_reward(const DevParams &p, Lds &l, int 
         if (p.buf.info) { p.buf.info[2 * (size_t)row] = wl; p.buf.info[2 * (size_t)row + 1] = ni; }
     }
 }
-

@@ -1,7 +1,5 @@
 // pcb_reset.h -- reset of one environment from the instance queue (k_reset and the in-launch reset of k_step)
 // Part of libpcbenv.so's single translation unit (included by pcbenv_kernels.hip); CDNA4 / gfx950 only.
-#pragma once
-#include "pcb_sampler.h"
 
 // ----------------------------------------------------------------------------------------------
 // reset (R:310-351, P:1544-1597, S:1487-1549, Q:74-113): header is in LDS; builds the new episode's state in
@@ -9,7 +7,7 @@
 // ----------------------------------------------------------------------------------------------
 // The next queued instance of environment e: header and 8-byte records, all loads issued together.
 struct InstRegs { int nc, nn, np; u64 comp; u64 pin[4]; };
-__device__ inline void fetch_instance(const DevParams &p, unsigned qcursor, int e, int lane, InstRegs &ir) {
+static __device__ inline void fetch_instance(const DevParams &p, unsigned qcursor, int e, int lane, InstRegs &ir) {
     const unsigned slot = qcursor % (unsigned)p.Q;
     const unsigned char *rec = p.queue + ((size_t)slot * p.B + e) * p.instStride;
     const int *ih = (const int *)rec;
@@ -20,7 +18,7 @@ __device__ inline void fetch_instance(const DevParams &p, unsigned qcursor, int 
     for (int r = 0; r < 4; r++) { const int q = lane + r * NT; ir.pin[r] = q < p.P ? load_agent(prec + q) : 0ull; }
 }
 
-template <int KIND, int WW, bool TRAJ> __device__ inline void reset_env(const DevParams &p, Lds &l, int e, int row, int lane) {
+template <int KIND, int WW, bool TRAJ> static __device__ inline void reset_env(const DevParams &p, Lds &l, int e, int row, int lane) {
     const int H = p.H, W = p.W, HW = H * W;
     const bool full = TRAJ && p.num_slots > 1;  // trajectory layout: the destination slot holds nothing of this environment yet
     lds_sync();
@@ -200,7 +198,7 @@ template <int KIND, int WW, bool TRAJ> __device__ inline void reset_env(const De
                 }
                 if (lane == 0) l.hdr->feat_gen = p.bind_gen;
                 if (!rows_cleared) {  // first reset after a bind: the full zero fill above must land before the row writes
-                    __syncthreads();
+                    store_drain_sync();
                     __threadfence_block();
                 }
                 for (int q = lane; q < np; q += NT) {
@@ -226,21 +224,4 @@ template <int KIND, int WW, bool TRAJ> __device__ inline void reset_env(const De
     lds_sync();
 }
 
-template <int KIND, int WW, int NW>
-__global__ __launch_bounds__(64 * NW) void k_reset(DevParams p, const unsigned char *__restrict__ mask) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int e = blockIdx.x, lane = threadIdx.x;
-    if (mask && !mask[e]) return;
-    load_state(smem, p, e, lane);  // cursor / episode survive; the old pins tell which feature rows to clear
-    Lds l = carve(smem, p);
-    const int row = out_row(p, p.slot, e);
-    reset_env<KIND, WW, true>(p, l, e, row, lane);
-    if (lane == 0) {
-        l.hdr->pre_action = 0u;  // the mask changed under any presampled action
-        p.buf.reward[row] = 0.0;
-        p.buf.done[row] = 0;
-        if (p.buf.info) { p.buf.info[2 * (size_t)row] = nan(""); p.buf.info[2 * (size_t)row + 1] = nan(""); }
-    }
-    store_state(smem, p, e, lane);
-}
 

@@ -1,16 +1,14 @@
 // pcb_reward.h -- float64 geometry of the routing reward: centroid routes, exact extent pre-filter, intersection count, wirelength
 // Part of libpcbenv.so's single translation unit (included by pcbenv_kernels.hip); CDNA4 / gfx950 only.
-#pragma once
-#include "pcb_device.h"
 
 // ----------------------------------------------------------------------------------------------
 // float64 geometry of the reward (one IEEE operation per operator, see file header)
 // ----------------------------------------------------------------------------------------------
 // S:1288-1301 euclidean_distance == np.linalg.norm == sqrt(ddot): sqrt(fma(dy, dy, dx*dx))
-__device__ inline double norm2(double dx, double dy) { return __dsqrt_rn(__fma_rn(dy, dy, __dmul_rn(dx, dx))); }
+static __device__ inline double norm2(double dx, double dy) { return __dsqrt_rn(__fma_rn(dy, dy, __dmul_rn(dx, dx))); }
 
 // S:653-702 is_intersect
-__device__ inline bool is_intersect(double x1, double y1, double x2, double y2, double x3, double y3, double x4, double y4) {
+static __device__ inline bool is_intersect(double x1, double y1, double x2, double y2, double x3, double y3, double x4, double y4) {
     if ((x1 == x3 && y1 == y3) || (x1 == x4 && y1 == y4) || (x2 == x3 && y2 == y3) || (x2 == x4 && y2 == y4)) return true;
     double det = (x1 - x2) * (y3 - y4) - (y1 - y2) * (x3 - x4);
     if (det == 0) return false;
@@ -34,7 +32,7 @@ struct SegView { double *X1, *Y1, *X2, *Y2, *D, *A, *DX, *DY, *cen; int *act, *n
 #define SEG_FIXED_BYTES(P) ((5 * (P) + 2 * PCBENV_MAX_NETS) * 8 + SEG_INTS(P) * 4)
 #define SEG_COUNT_BYTES(P, NW) (3 * (P) * 8 + (P) * 4 + PAIR_ENTRIES_PER_WAVE * 2 * (NW))
 #define SEG_LDS_BYTES(P, NW, beam) (((SEG_FIXED_BYTES(P) + 7) & ~7) + ((beam) > SEG_COUNT_BYTES(P, NW) ? (beam) : SEG_COUNT_BYTES(P, NW)))
-__device__ inline SegView seg_view(double *seg, int P) {
+static __device__ inline SegView seg_view(double *seg, int P) {
     SegView v;
     v.X1 = seg; v.Y1 = seg + P; v.X2 = seg + 2 * P; v.Y2 = seg + 3 * P; v.D = seg + 4 * P;
     v.cen = seg + 5 * P;                              // cx[MAX_NETS], cy[MAX_NETS]
@@ -50,7 +48,7 @@ __device__ inline SegView seg_view(double *seg, int P) {
 
 // net_pins offsets (self.pins is net-major) and S:1229-1241 get_centroid per net: np.mean of an integer array =
 // (exact integer sum, as float64) / n -- the sums are gathered with LDS integer atomics (order-free because exact).
-__device__ inline void net_offsets_and_centroids(const SegView &v, const EnvHdr *hdr, const PinRec *pins, int lane) {
+static __device__ inline void net_offsets_and_centroids(const SegView &v, const EnvHdr *hdr, const PinRec *pins, int lane) {
     const int np = hdr->npins, nn = hdr->nnets;
     lds_sync();  // the segment area aliases the class map of emit_pin_grid
     for (int n = lane; n < 2 * PCBENV_MAX_NETS; n += NT) v.nsum[n] = 0;
@@ -72,7 +70,7 @@ __device__ inline void net_offsets_and_centroids(const SegView &v, const EnvHdr 
 }
 
 // S:1243-1271 route_pins_centroid: (pin, centroid) per pin; a 2-pin net is the single segment (p0, p1)
-__device__ inline void build_centroid_segments(const SegView &v, const EnvHdr *hdr, const PinRec *pins, int lane) {
+static __device__ inline void build_centroid_segments(const SegView &v, const EnvHdr *hdr, const PinRec *pins, int lane) {
     const int np = hdr->npins;
     for (int q = lane; q < np; q += NT) {
         const int n = pins[q].net, s = v.nstart[n], cnt = v.nstart[n + 1] - s;
@@ -91,7 +89,7 @@ __device__ inline void build_centroid_segments(const SegView &v, const EnvHdr *h
 // Written without branches so that several candidates per lane can be in flight at once (the count is bound by
 // the LDS and float64 division latency of one wavefront, not by issue slots): det == 0 gives inf / NaN
 // coordinates, which is harmless and masked by the explicit test.
-__device__ inline bool slots_intersect(const SegView &v, int i, int j) {
+static __device__ inline bool slots_intersect(const SegView &v, int i, int j) {
     const double x1 = v.X1[i], y1 = v.Y1[i], x2 = v.X2[i], y2 = v.Y2[i];
     const double x3 = v.X1[j], y3 = v.Y1[j], x4 = v.X2[j], y4 = v.Y2[j];
     const double dxi = v.DX[i], dyi = v.DY[i], dxj = v.DX[j], dyj = v.DY[j];
@@ -110,12 +108,12 @@ __device__ inline bool slots_intersect(const SegView &v, int i, int j) {
 // integers (floor of the minimum, ceil of the maximum; coordinates are in [0, 127]), four bytes per segment, so
 // the filter is one LDS word per segment and a few integer compares; a pair it lets through is decided by the
 // full float64 test, a pair it rejects has disjoint real extents.  Saves the two float64 divisions.
-__device__ inline unsigned pack_extents(double x1, double y1, double x2, double y2) {
+static __device__ inline unsigned pack_extents(double x1, double y1, double x2, double y2) {
     const unsigned xl = (unsigned)floor(fmin(x1, x2)), xh = (unsigned)ceil(fmax(x1, x2));
     const unsigned yl = (unsigned)floor(fmin(y1, y2)), yh = (unsigned)ceil(fmax(y1, y2));
     return xl | (xh << 8) | (yl << 16) | (yh << 24) | 0x80000000u;  // bit 31 = slot carries a segment
 }
-__device__ inline bool extents_overlap(unsigned a, unsigned b) {  // branch-free
+static __device__ inline bool extents_overlap(unsigned a, unsigned b) {  // branch-free
     const unsigned xl = max(a & 0xFFu, b & 0xFFu), xh = min((a >> 8) & 0xFFu, (b >> 8) & 0xFFu);
     const unsigned yl = max((a >> 16) & 0xFFu, (b >> 16) & 0xFFu), yh = min((a >> 24) & 0x7Fu, (b >> 24) & 0x7Fu);
     return ((a & b & 0x80000000u) != 0) & (xl <= xh) & (yl <= yh);
@@ -124,7 +122,7 @@ __device__ inline bool extents_overlap(unsigned a, unsigned b) {  // branch-free
 // Full test on candidates [0, n) of a wavefront's buffer, two per lane and step so that their LDS reads and
 // divisions overlap.
 typedef __attribute__((address_space(3))) unsigned short lds_u16;  // keeps the buffer accesses ds_* instead of flat_*
-__device__ inline int count_candidates(const SegView &v, const volatile lds_u16 *buf, int n, int wl_lane) {
+static __device__ inline int count_candidates(const SegView &v, const volatile lds_u16 *buf, int n, int wl_lane) {
     int cnt = 0;
     for (int base = 0; base < n; base += 2 * WAVE) {
         const int i0 = base + wl_lane, i1 = i0 + WAVE;
@@ -145,7 +143,7 @@ __device__ inline int count_candidates(const SegView &v, const volatile lds_u16 
 // the full float64 test in dense batches of 128.  The wirelength is summed sequentially in route order (bit-exact
 // with the reference's python float loop).
 // count_prepare reads the pins, count_finish only the segment zone.
-__device__ inline void count_prepare(const SegView &v, int np, int lane) {
+static __device__ inline void count_prepare(const SegView &v, int np, int lane) {
     int *total_cnt = v.nstart + PCBENV_MAX_NETS + 1;  // spare slot behind nstart[0..MAX_NETS]
     for (int q = lane; q < np; q += NT) {
         const double x1 = v.X1[q], y1 = v.Y1[q], x2 = v.X2[q], y2 = v.Y2[q];
@@ -155,7 +153,9 @@ __device__ inline void count_prepare(const SegView &v, int np, int lane) {
     if (lane == 0) *total_cnt = 0;
     lds_sync();
 }
-__device__ inline void count_finish(const DevParams &p, const SegView &v, int np_, int nn_, int lane, double *wirelength, int *nintersections) {
+// (part, nparts): the sweep steps are dealt to `nparts` teams of a launch (the environment's own wavefront and its reward
+// helpers, see run_env), this team being number `part`; *nintersections is then this team's share of the count.
+static __device__ inline void count_finish(const DevParams &p, const SegView &v, int np_, int nn_, int lane, int part, int nparts, double *wirelength, int *nintersections) {
     int *total_cnt = v.nstart + PCBENV_MAX_NETS + 1;
     const int np = __builtin_amdgcn_readfirstlane(np_), nn = __builtin_amdgcn_readfirstlane(nn_);
     STAMP(12);
@@ -165,13 +165,16 @@ __device__ inline void count_finish(const DevParams &p, const SegView &v, int np
     const int wl_lane = lane & 63, wave = lane >> 6, nwaves = NT / WAVE;
     volatile lds_u16 *buf = (volatile lds_u16 *)(v.pairs + wave * PAIR_ENTRIES_PER_WAVE);  // wave-synchronous: written and read by different lanes
     int cnt = 0, nbuf = 0, step = 0;
+    int pm = 0, pq = 0;  // step % nparts, step / nparts (kept incrementally: no division by a run-time value)
     for (int n = 1; n < nn; n++) {  // wave-uniform; net 0 has no earlier net
         const int s = __builtin_amdgcn_readfirstlane(v.nstart[n]), c = __builtin_amdgcn_readfirstlane(v.nstart[n + 1]) - s;
         const int R = s * c;                         // pairs (i, j): i in [0, s) earlier-net slot, j in [s, s + c)
         const unsigned magic = (65536u + (unsigned)c - 1u) / (unsigned)max(c, 1);  // r / c == (r * magic) >> 16 for r < 4160, c <= 16
         // four 64-pair groups per sweep step: their LDS reads go out together and the loop overhead is paid once
         for (int base = 0; base < R; base += 4 * WAVE, step++) {
-            if ((step & (nwaves - 1)) != wave) continue;  // nwaves is 1 or 4
+            const bool mine = pm == part && (pq & (nwaves - 1)) == wave;  // nwaves is 1 or 4
+            if (++pm == nparts) { pm = 0; pq++; }
+            if (!mine) continue;
             unsigned bi[4], bj[4]; int pi[4], pj[4];
             #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -230,15 +233,15 @@ __device__ inline void count_finish(const DevParams &p, const SegView &v, int np
     *nintersections = *total_cnt;
     lds_sync();
 }
-__device__ inline void count_and_length(const DevParams &p, const SegView &v, const EnvHdr *hdr, const PinRec *pins, int lane,
+static __device__ inline void count_and_length(const DevParams &p, const SegView &v, const EnvHdr *hdr, const PinRec *pins, int lane, int part, int nparts,
                                         double *wirelength, int *nintersections) {
     const int np = hdr->npins, nn = hdr->nnets;
     count_prepare(v, np, lane);
-    count_finish(p, v, np, nn, lane, wirelength, nintersections);
+    count_finish(p, v, np, nn, lane, part, nparts, wirelength, nintersections);
 }
 
-__device__ inline void route_centroid(const DevParams &p, const EnvHdr *hdr, const PinRec *pins, double *seg,
-                                      int lane, double *wirelength, int *nintersections) {
+static __device__ inline void route_centroid(const DevParams &p, const EnvHdr *hdr, const PinRec *pins, double *seg,
+                                      int lane, int part, int nparts, double *wirelength, int *nintersections) {
     const SegView v = seg_view(seg, p.P);
     net_offsets_and_centroids(v, hdr, pins, lane);
     STAMP(5);
@@ -246,7 +249,7 @@ __device__ inline void route_centroid(const DevParams &p, const EnvHdr *hdr, con
     STAMP(6);
     count_prepare(v, hdr->npins, lane);
     STAMP(22);
-    count_finish(p, v, hdr->npins, hdr->nnets, lane, wirelength, nintersections);
+    count_finish(p, v, hdr->npins, hdr->nnets, lane, part, nparts, wirelength, nintersections);
     STAMP(8);
 }
 

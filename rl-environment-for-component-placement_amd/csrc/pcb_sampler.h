@@ -1,17 +1,15 @@
 // pcb_sampler.h -- uniform legal-action sampler (k_sample and the fused sampler of k_step)
 // Part of libpcbenv.so's single translation unit (included by pcbenv_kernels.hip); CDNA4 / gfx950 only.
-#pragma once
-#include "pcb_observe.h"
 
 // ----------------------------------------------------------------------------------------------
 // uniform legal-action sampler (rollout driver; agent/random/random_policy_*.py counterpart)
 // ----------------------------------------------------------------------------------------------
-__device__ inline u64 mix64(u64 z) {  // splitmix64 finaliser
+static __device__ inline u64 mix64(u64 z) {  // splitmix64 finaliser
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return z ^ (z >> 31);
 }
-__device__ inline int select_bit(u64 w, int k) {  // position of the k-th (0-based) set bit: binary search on popcounts
+static __device__ inline int select_bit(u64 w, int k) {  // position of the k-th (0-based) set bit: binary search on popcounts
     int pos = 0;
     #pragma unroll
     for (int width = 32; width >= 1; width >>= 1) {
@@ -23,7 +21,7 @@ __device__ inline int select_bit(u64 w, int k) {  // position of the k-th (0-bas
 // Uniform draw over the set bits of the legal-action bit mask vm (planes 0/1; pin kinds also mirror them as
 // orientations 2/3): per-lane popcounts of a contiguous run of words, wave prefix sum, the owner lane selects
 // the k-th set bit.  rnd = mix64(mix64(seed ^ GOLDEN*(env+1)) + step); pick = hi32(rnd) * n >> 32.
-__device__ inline void sample_action(const u64 *vm, const DevParams &p, int genv, int lane, u64 seed, u64 step_index,
+static __device__ inline void sample_action(const u64 *vm, const DevParams &p, int genv, int lane, u64 seed, u64 step_index,
                                      int *o, int *x, int *y) {
     const int WW = p.WW, plane = p.H * WW;
     const int words = (p.kind == PCBENV_SQUARE ? 1 : 2) * plane;
@@ -57,16 +55,5 @@ __device__ inline void sample_action(const u64 *vm, const DevParams &p, int genv
     *o = pl + 2 * rep;
     *x = WW == 1 ? rw : rw >> 1;
     *y = (rw - *x * WW) * 64 + bit;
-}
-__global__ __launch_bounds__(WAVE) void k_sample(DevParams p, int *__restrict__ actions, int fmt, u64 seed,
-                                                 u64 first_env, u64 step_index) {
-    const int e = blockIdx.x, lane = threadIdx.x;
-    const u64 *vm = (const u64 *)(p.state + (size_t)e * p.stateStride + p.offVm);
-    int o, x, y;
-    sample_action(vm, p, (int)first_env + e, lane, seed, step_index, &o, &x, &y);
-    if (lane == 0) {
-        if (fmt == PCBENV_ACTION_FLAT) actions[e] = o * p.H * p.W + x * p.W + y;
-        else { actions[3 * e] = o; actions[3 * e + 1] = x; actions[3 * e + 2] = y; }
-    }
 }
 

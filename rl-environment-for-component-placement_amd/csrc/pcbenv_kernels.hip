@@ -25,7 +25,9 @@
 #include <vector>
 
 #include "pcbenv.h"
-#include "pcb_step.h"  // -> pcb_reset.h -> pcb_sampler.h -> pcb_observe.h -> pcb_beam.h -> pcb_reward.h -> pcb_device.h
+#define PCB_HOST_TU
+#include "pcb_kernels.h"  // k_sample, k_cursor_range (the per-kind kernels are instantiated in pcb_kind_*.hip)
+#include "pcb_launch.h"
 #include "pcb_geninst.h"
 
 // ==============================================================================================
@@ -48,6 +50,12 @@ struct pcbenv {
     hipStream_t gen_stream;
     hipEvent_t ev_snap, ev_fill;
     long long since_waited, since_outstanding;
+    int gen_lanes;      // PCBENV_OPT_GEN_LANES: 0 = the narrowest group the configuration allows
+    // terminal list (Team<>::run_env): launch counter, list entries that get helper teams per launch (0 = none)
+    unsigned seq;
+    int term_wgs;
+    unsigned char *state_buf[2];  // double-buffered state blocks: dp.state is the current one, a step launch writes the other
+    int state_cur;
     char err[256];
 };
 
@@ -75,6 +83,7 @@ struct DeviceGuard {
 };
 #define DEVICE_GUARD(env) DeviceGuard guard_((env)->device); if (!guard_.ok) return fail(env, PCBENV_EHIP, "hipSetDevice failed")
 
+#define PCBENV_TERM_CAP_MAX 4096  // entries per ring of the terminal list = the most terminal workgroups of a launch
 static int align16(long long v) { return (int)((v + 15) & ~15ll); }
 
 extern "C" int pcbenv_abi_version(void) { return PCBENV_ABI_VERSION; }
@@ -179,10 +188,8 @@ extern "C" int pcbenv_create(const pcbenv_config *cfg, int device, pcbenv **out)
     {   // streaming stores when one launch writes well beyond the 256 MiB Infinity Cache (see STORE16)
         const long long cells = (long long)c.height * c.width;
         const long long per_env = (c.flags & PCBENV_FLAG_INCREMENTAL_OBS) ? cells * d.O : cells * (1 + d.O + (c.kind == PCBENV_SPATIAL ? d.K : 0));
-        long long threshold_mb = 256;
-        if (const char *ev = getenv("PCBENV_STREAM_THRESHOLD_MB")) threshold_mb = atoll(ev);
-        d.stream_stores = per_env * c.num_envs > threshold_mb * (1ll << 20);
-        env->cell_bytes_per_env = per_env; env->stream_threshold = threshold_mb * (1ll << 20);
+        env->cell_bytes_per_env = per_env; env->stream_threshold = 256ll << 20;  // PCBENV_OPT_STREAM_THRESHOLD_BYTES
+        d.stream_stores = per_env * c.num_envs > env->stream_threshold;
     }
     d.w_wl = c.weight_wirelength; d.w_int = c.weight_num_intersections;
     d.area = (double)(c.height * c.width);
@@ -220,12 +227,28 @@ extern "C" int pcbenv_create(const pcbenv_config *cfg, int device, pcbenv **out)
         int cls = c.kind == PCBENV_SPATIAL ? (d.H * d.W > d.C * d.mp * 6 + 4 ? d.H * d.W : d.C * d.mp * 6 + 4) : 0, seg = is_pin_kind(c.kind) ? SEG_LDS_BYTES(d.P, env->threads / 64, beam) : 0;
         d.ldsBytes = align16(d.ldsCls + (cls > seg ? cls : seg));
     }
+#ifdef PCBENV_EXPERIMENTS
     { const char *ev = getenv("PCBENV_LDS_MIN"); if (ev && atoi(ev) > d.ldsBytes) d.ldsBytes = align16(atoi(ev)); }  // occupancy experiments
+#endif
+    // Terminal list: on for one-wavefront teams with instances (Team<>::run_env); B / 8 entries cover twice the
+    // 1 / max_num_components of the batch that ends an episode per launch when the phases are spread evenly over a
+    // 16-component episode (PCBENV_OPT_TERMINAL_TEAMS changes or disables it).
+    env->seq = 0;
+    env->term_wgs = 0;
+    if (env->threads == 64 && is_pin_kind(c.kind)) {
+        int wgs = (c.num_envs / 8 + (int)TERM_SHARDS - 1) & ~((int)TERM_SHARDS - 1);
+        env->term_wgs = wgs < (int)TERM_SHARDS ? (int)TERM_SHARDS : wgs > PCBENV_TERM_CAP_MAX ? PCBENV_TERM_CAP_MAX : wgs;
+    }
+    d.term_cap = env->term_wgs;  // one list entry per set of helper teams
+    d.term_hpe = REWARD_PARTS;  // reward helpers per entry (pcb_step.h REWARD_PARTS)
     DeviceGuard guard_(device);
     if (!guard_.ok) { int r = fail(0, PCBENV_EHIP, "hipSetDevice failed (no such device?)"); delete env; return r; }
     size_t sbytes = (size_t)d.stateStride * d.B, qbytes = (size_t)d.instStride * d.B * d.Q;
-    if (hipMalloc((void **)&d.state, sbytes) != hipSuccess || hipMalloc((void **)&d.queue, qbytes ? qbytes : 16) != hipSuccess ||
-        hipMalloc((void **)&d.cursor_pub, 4 * (size_t)d.B) != hipSuccess) {
+    if (hipMalloc((void **)&env->state_buf[0], sbytes) != hipSuccess || hipMalloc((void **)&env->state_buf[1], sbytes) != hipSuccess ||
+        hipMalloc((void **)&d.queue, qbytes ? qbytes : 16) != hipSuccess ||
+        hipMalloc((void **)&d.cursor_pub, 4 * (size_t)d.B) != hipSuccess ||
+        hipMalloc((void **)&d.term_list, 4 * (size_t)4 * PCBENV_TERM_CAP_MAX) != hipSuccess || hipMalloc((void **)&d.term_cnt, 4 * TERM_SHARDS * TERM_CNT_STRIDE * 4) != hipSuccess || hipMalloc((void **)&d.term_arrive, 8 * (size_t)PCBENV_TERM_CAP_MAX) != hipSuccess ||
+        hipMalloc((void **)&d.term_mark, 16 * (size_t)d.B) != hipSuccess) {
         int r = fail(0, PCBENV_EHIP, "hipMalloc failed");
         pcbenv_destroy(env);
         return r;
@@ -233,9 +256,15 @@ extern "C" int pcbenv_create(const pcbenv_config *cfg, int device, pcbenv **out)
 #ifdef PCBENV_STAMPS
     { const char *ev = getenv("PCBENV_STAMPS"); if (ev && ev[0] == '1') { hipMalloc((void **)&d.dbg, (size_t)d.B * 32 * 8); hipMemset(d.dbg, 0, (size_t)d.B * 32 * 8); } }
 #endif
-    hipMemset(d.state, 0, sbytes);
+    hipMemset(env->state_buf[0], 0, sbytes);
+    hipMemset(env->state_buf[1], 0, sbytes);
+    env->state_cur = 0;
+    d.state = d.state_out = env->state_buf[0];
     hipMemset(d.queue, 0, qbytes ? qbytes : 16);
     hipMemset(d.cursor_pub, 0, 4 * (size_t)d.B);
+    hipMemset(d.term_cnt, 0, 4 * TERM_SHARDS * TERM_CNT_STRIDE * 4);
+    hipMemset(d.term_arrive, 0, 8 * (size_t)PCBENV_TERM_CAP_MAX);
+    hipMemset(d.term_mark, 0, 16 * (size_t)d.B);
     hipDeviceSynchronize();
     *out = env;
     return PCBENV_OK;
@@ -251,11 +280,46 @@ extern "C" void pcbenv_destroy(pcbenv *env) {
         if (env->gp.gen) hipFree(env->gp.gen);
         if (env->gp.produced) hipFree(env->gp.produced);
     }
-    if (env->dp.state) hipFree(env->dp.state);
+    if (env->state_buf[0]) hipFree(env->state_buf[0]);
+    if (env->state_buf[1]) hipFree(env->state_buf[1]);
     if (env->dp.queue) hipFree(env->dp.queue);
     if (env->dp.cursor_pub) hipFree(env->dp.cursor_pub);
+    if (env->dp.term_list) hipFree(env->dp.term_list);
+    if (env->dp.term_cnt) hipFree(env->dp.term_cnt);
+    if (env->dp.term_mark) hipFree(env->dp.term_mark);
+    if (env->dp.term_arrive) hipFree(env->dp.term_arrive);
     if (env->scratch) hipFree(env->scratch);
     delete env;
+}
+
+extern "C" int pcbenv_set_option(pcbenv *env, int32_t option, int64_t value) {
+    if (!env) return fail(0, PCBENV_EINVAL, "null handle");
+    switch (option) {
+    case PCBENV_OPT_STREAM_THRESHOLD_BYTES:
+        if (value < 0) return fail(env, PCBENV_EINVAL, "threshold must not be negative");
+        env->stream_threshold = value;
+        env->dp.stream_stores = env->cell_bytes_per_env * env->dp.B > env->stream_threshold;
+        return PCBENV_OK;
+    case PCBENV_OPT_TERMINAL_TEAMS:
+        if (value < 0 || value > PCBENV_TERM_CAP_MAX) return fail(env, PCBENV_EINVAL, "terminal-list entries must be in [0, 4096]");
+        if (value > 0 && (env->threads != 64 || !is_pin_kind(env->cfg.kind)))
+            return fail(env, PCBENV_EINVAL, "reward helpers need one-wavefront environments with a routing reward");
+        value = (value + TERM_SHARDS - 1) & ~(long long)(TERM_SHARDS - 1);
+        env->term_wgs = (int)value;
+        env->dp.term_cap = (int)value;
+        env->seq += 2;  // the lists built so far were laid out for the old capacity: no mark matches the next launch
+        return PCBENV_OK;
+    case PCBENV_OPT_GEN_GRID:
+        if (value < 1) return fail(env, PCBENV_EINVAL, "generator grid must be at least 1");
+        env->gen_grid = (int)value;
+        return PCBENV_OK;
+    case PCBENV_OPT_GEN_LANES:
+        if (env->gen_on) return fail(env, PCBENV_ESTATE, "set the generator's group width before enabling it");
+        if (value != 0 && value != 16 && value != 32 && value != 64) return fail(env, PCBENV_EINVAL, "generator lanes per environment: 0, 16, 32 or 64");
+        env->gen_lanes = (int)value;
+        return PCBENV_OK;
+    }
+    return fail(env, PCBENV_EINVAL, "unknown option");
 }
 
 extern "C" int pcbenv_bind_buffers_slots(pcbenv *env, const pcbenv_buffers *b, int32_t num_slots);
@@ -292,6 +356,8 @@ extern "C" int pcbenv_load_instances(pcbenv *env, const int32_t *env_ids, int32_
     if (!env || !host_tables) return fail(env, PCBENV_EINVAL, "null argument");
     const DevParams &d = env->dp;
     if (env->cfg.kind == PCBENV_SQUARE) return PCBENV_OK;  // the square env has no instance
+    // refused before anything is copied: the generator owns the records, and k_gen_fill may be writing this very slot
+    if (env->gen_on) return fail(env, PCBENV_ESTATE, "the on-device generator owns the queue (pcbenv_instgen_device_enable)");
     if (slot < 0 || slot >= d.Q || n < 0 || n > d.B) return fail(env, PCBENV_EINVAL, "slot or count out of range");
     DEVICE_GUARD(env);
     const long long src_stride = pcbenv_instance_stride(&env->cfg);
@@ -339,50 +405,58 @@ extern "C" int pcbenv_load_instances(pcbenv *env, const int32_t *env_ids, int32_
         }
     }
     HIP_TRY(env, hipStreamSynchronize(s));
-    if (env->gen_on) return fail(env, PCBENV_ESTATE, "the on-device generator owns the queue (pcbenv_instgen_device_enable)");
     if (!env_ids && n == d.B) env->loaded_slots[slot >> 6] |= 1ull << (slot & 63);  // partial loads: caller's responsibility
     return PCBENV_OK;
 }
 
-template <int KIND> static int launch_reset(pcbenv *env, const uint8_t *mask, hipStream_t s) {
-    const DevParams &d = env->dp;
-#define LAUNCH_RESET(WW_, NW_) hipLaunchKernelGGL((k_reset<KIND, WW_, NW_>), dim3(d.B), dim3(64 * NW_), d.ldsBytes, s, d, mask)
-    if (d.WW == 1) { if (env->threads == 64) LAUNCH_RESET(1, 1); else LAUNCH_RESET(1, 4); }
-    else { if (env->threads == 64) LAUNCH_RESET(2, 1); else LAUNCH_RESET(2, 4); }
-    return 0;
+static int launch_reset(pcbenv *env, const uint8_t *mask, hipStream_t s) {
+    ResetLaunch a{env->dp, mask, env->threads, s};
+    a.d.seq = env->seq;  // the next step launch is seq + 1: a reset takes its environments off that launch's terminal list
+    switch (env->cfg.kind) {
+    case PCBENV_SQUARE: return pcb_launch_reset_square(a);
+    case PCBENV_RECT: return pcb_launch_reset_rect(a);
+    case PCBENV_PIN: return pcb_launch_reset_pin(a);
+    default: return pcb_launch_reset_spatial(a);
+    }
 }
-template <int KIND> static int launch_step(pcbenv *env, int *actions, int fmt, int sampled, u64 seed, u64 first_env,
-                                           u64 step_index, int num_steps, hipStream_t s) {
-    DevParams d = env->dp;
+// Every step launch has a number (DevParams::seq); see k_step_mixed for what the terminal list is.
+static int dispatch_step(pcbenv *env, int *actions, int fmt, int sampled, u64 seed, u64 first_env, u64 step_index, int num_steps, hipStream_t s) {
+    StepLaunch a;
+    a.d = env->dp;
+    DevParams &d = a.d;
+    a.actions = actions; a.fmt = fmt; a.sampled = sampled; a.seed = seed; a.first_env = first_env; a.step_index = step_index;
+    a.num_steps = num_steps; a.threads = env->threads; a.stream = s;
     // lean build (in-place layout, one transition, store policy compiled in) or the trajectory / rollout build
-    const bool traj = d.num_slots > 1 || num_steps > 1;
+    a.traj = d.num_slots > 1 || num_steps > 1;
     // A persistent rollout into the trajectory layout writes min(num_steps, num_slots) slots per launch, none of which is
     // read before the launch ends: the policy is chosen on what the LAUNCH writes (in place, the steps of a rollout
     // overwrite the same lines and the per-transition choice of pcbenv_create stands).
-    if (traj && d.num_slots > 1) {
+    if (a.traj && d.num_slots > 1) {
         const long long slots = num_steps < d.num_slots ? num_steps : d.num_slots;
         d.stream_stores = env->cell_bytes_per_env * d.B * slots > env->stream_threshold;
     }
-#define LAUNCH_STEP_(WW_, NW_, RT_, ST_, TJ_) hipLaunchKernelGGL((k_step<KIND, WW_, NW_, RT_, ST_, TJ_>), dim3(d.B), dim3(64 * NW_), d.ldsBytes, s, d, actions, fmt, sampled, seed, first_env, step_index, num_steps)
-#define LAUNCH_STEP(WW_, NW_, RT_) do { if (traj) LAUNCH_STEP_(WW_, NW_, RT_, false, true); else if (d.stream_stores) LAUNCH_STEP_(WW_, NW_, RT_, true, false); else LAUNCH_STEP_(WW_, NW_, RT_, false, false); } while (0)
-    constexpr bool PINK = (KIND == PCBENV_PIN || KIND == PCBENV_SPATIAL);
-    const bool routes = PINK && env->cfg.reward_type != PCBENV_REWARD_CENTROID;
-    if (routes) {
-        if (d.WW == 1) { if (env->threads == 64) LAUNCH_STEP(1, 1, PINK); else LAUNCH_STEP(1, 4, PINK); }
-        else { if (env->threads == 64) LAUNCH_STEP(2, 1, PINK); else LAUNCH_STEP(2, 4, PINK); }
-    } else {
-        if (d.WW == 1) { if (env->threads == 64) LAUNCH_STEP(1, 1, false); else LAUNCH_STEP(1, 4, false); }
-        else { if (env->threads == 64) LAUNCH_STEP(2, 1, false); else LAUNCH_STEP(2, 4, false); }
-    }
-    return 0;
-}
-static int dispatch_step(pcbenv *env, int *actions, int fmt, int sampled, u64 seed, u64 first_env, u64 step_index, int num_steps, hipStream_t s) {
+    a.routes = is_pin_kind(env->cfg.kind) && env->cfg.reward_type != PCBENV_REWARD_CENTROID;
+    if (++env->seq == 0u) env->seq = 1u;  // 0 is "not listed" in the marks
+    d.seq = env->seq;
+    // A launch that is being captured into a hipGraph will be replayed with these very arguments: no launch number,
+    // no buffer swap -- it runs without helpers, keeps no list and works on the state blocks in place.
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+    d.term_wgs = (num_steps == 1 && !capturing) ? env->term_wgs : 0;  // reward helpers: one transition per launch only
+    if (capturing) d.term_cap = 0;
+    // double-buffered state blocks: read the current ones, write the others
+    d.state = env->state_buf[env->state_cur];
+    d.state_out = env->state_buf[env->state_cur ^ (capturing ? 0 : 1)];
+    int rc;
     switch (env->cfg.kind) {
-    case PCBENV_SQUARE: return launch_step<PCBENV_SQUARE>(env, actions, fmt, sampled, seed, first_env, step_index, num_steps, s);
-    case PCBENV_RECT: return launch_step<PCBENV_RECT>(env, actions, fmt, sampled, seed, first_env, step_index, num_steps, s);
-    case PCBENV_PIN: return launch_step<PCBENV_PIN>(env, actions, fmt, sampled, seed, first_env, step_index, num_steps, s);
-    default: return launch_step<PCBENV_SPATIAL>(env, actions, fmt, sampled, seed, first_env, step_index, num_steps, s);
+    case PCBENV_SQUARE: rc = pcb_launch_step_square(a); break;
+    case PCBENV_RECT: rc = pcb_launch_step_rect(a); break;
+    case PCBENV_PIN: rc = pcb_launch_step_pin(a); break;
+    default: rc = pcb_launch_step_spatial(a); break;
     }
+    if (!capturing) env->state_cur ^= 1;
+    env->dp.state = env->dp.state_out = env->state_buf[env->state_cur];  // what k_reset / k_sample / get_state work on, in place
+    return rc;
 }
 
 static int pre_launch(pcbenv *env) {
@@ -403,12 +477,7 @@ extern "C" int pcbenv_reset(pcbenv *env, const uint8_t *mask_dev, void *stream) 
     hipStream_t s = (hipStream_t)stream;
     rc = gen_before_launch(env, 1, s);
     if (rc) return rc;
-    switch (env->cfg.kind) {
-    case PCBENV_SQUARE: launch_reset<PCBENV_SQUARE>(env, mask_dev, s); break;
-    case PCBENV_RECT: launch_reset<PCBENV_RECT>(env, mask_dev, s); break;
-    case PCBENV_PIN: launch_reset<PCBENV_PIN>(env, mask_dev, s); break;
-    default: launch_reset<PCBENV_SPATIAL>(env, mask_dev, s); break;
-    }
+    launch_reset(env, mask_dev, s);
     HIP_TRY(env, hipGetLastError());
     gen_after_launch(env, 1, s);
     return PCBENV_OK;
@@ -433,7 +502,7 @@ static int check_queue(pcbenv *env) {
 // kernels; the wait is a stream-side event wait, never a host synchronisation.
 // one refill launch: 64 / G environments per wavefront (gen_group_lanes), capped grid
 static void gen_launch_fill(pcbenv *env, hipStream_t s, bool whole_batch) {
-    const int G = gen_group_lanes(env->gp.C, env->cfg.max_num_nets, env->gp.P), epw = WAVE / G;
+    const int G = gen_group_lanes(env->gp.C, env->cfg.max_num_nets, env->gp.P, env->gen_lanes), epw = WAVE / G;
     int grid = (env->dp.B + epw - 1) / epw;
     if (!whole_batch && grid > env->gen_grid) grid = env->gen_grid;
     const size_t lds = GEN_LDS_BYTES(env->gp.instStride, G);
@@ -503,7 +572,6 @@ extern "C" int pcbenv_instgen_device_enable(pcbenv *env, const uint32_t *seeds_h
     HIP_TRY(env, hipEventCreateWithFlags(&env->ev_fill, hipEventDisableTiming));
     const dim3 grid((d.B + WAVE - 1) / WAVE);
     hipLaunchKernelGGL(k_gen_seed, grid, dim3(WAVE), 0, s, g, seeds_dev);
-    env->gen_grid = GEN_MAX_GRID;
     gen_launch_fill(env, s, true);  // the whole queue, before anything can consume it
     HIP_TRY(env, hipGetLastError());
     HIP_TRY(env, hipStreamSynchronize(s));
@@ -511,8 +579,7 @@ extern "C" int pcbenv_instgen_device_enable(pcbenv *env, const uint32_t *seeds_h
     env->dp.gen_produced = g.produced;
     env->dp.gen_errors = g.produced + d.B;  // one word behind the counters
     HIP_TRY(env, hipMemsetAsync(env->dp.gen_errors, 0, 4, s));
-    env->gen_grid = GEN_MAX_GRID;
-    if (const char *ev = getenv("PCBENV_GEN_GRID")) { const int v = atoi(ev); if (v >= 1) env->gen_grid = v; }
+    if (env->gen_grid < 1) env->gen_grid = GEN_MAX_GRID;  // unless PCBENV_OPT_GEN_GRID set it
     env->gen_on = true; env->gen_outstanding = false;
     env->since_waited = 0; env->since_outstanding = 0;
     return PCBENV_OK;

@@ -12,10 +12,11 @@ PCBENV_OK, PCBENV_EINVAL, PCBENV_ELIMIT, PCBENV_EHIP, PCBENV_ESTATE = 0, -1, -2,
 ACTION_TUPLE, ACTION_FLAT = 0, 1
 FLAG_INCREMENTAL_OBS = 1
 FLAG_AUTO_RESET = 2
-ABI_VERSION = 2
+ABI_VERSION = 3
+OPT_STREAM_THRESHOLD_BYTES, OPT_TERMINAL_TEAMS, OPT_GEN_GRID, OPT_GEN_LANES = 1, 2, 3, 4
 
 EXPORTS = ("pcbenv_abi_version", "pcbenv_create", "pcbenv_destroy", "pcbenv_last_error",
-           "pcbenv_instance_stride", "pcbenv_max_total_pins", "pcbenv_bind_buffers", "pcbenv_bind_buffers_slots", "pcbenv_select_slot",
+           "pcbenv_instance_stride", "pcbenv_max_total_pins", "pcbenv_set_option", "pcbenv_bind_buffers", "pcbenv_bind_buffers_slots", "pcbenv_select_slot",
            "pcbenv_load_instances", "pcbenv_reset", "pcbenv_step", "pcbenv_sample_actions", "pcbenv_step_sampled", "pcbenv_rollout_sampled",
            "pcbenv_mask_bits", "pcbenv_state_bytes", "pcbenv_get_state", "pcbenv_set_state", "pcbenv_queue_cursors",
            "pcbenv_instgen_device_enable", "pcbenv_instgen_device_status", "pcbenv_get_instances",
@@ -62,6 +63,7 @@ def load():
     L.pcbenv_instance_stride.restype = C.c_int64
     L.pcbenv_max_total_pins.argtypes = [C.POINTER(PcbenvConfig)]
     L.pcbenv_max_total_pins.restype = C.c_int32
+    L.pcbenv_set_option.argtypes = [C.c_void_p, C.c_int32, C.c_int64]
     L.pcbenv_bind_buffers.argtypes = [C.c_void_p, C.POINTER(PcbenvBuffers)]
     L.pcbenv_bind_buffers_slots.argtypes = [C.c_void_p, C.POINTER(PcbenvBuffers), C.c_int32]
     L.pcbenv_select_slot.argtypes = [C.c_void_p, C.c_int32]

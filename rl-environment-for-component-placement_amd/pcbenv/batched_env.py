@@ -60,10 +60,12 @@ class BatchedPlacementEnv:
     def __init__(self, cfg: EnvConfig, num_envs: int, device="cuda:0", queue_depth: int = 1,
                  run_seed: int = 0, first_env_index: int = 0, incremental_obs: bool = False,
                  auto_reset: bool = False, threads_per_env: int = 0,
-                 mask_marginals: bool = False, num_slots: int = 1):
+                 mask_marginals: bool = False, num_slots: int = 1, options: Optional[Dict[str, int]] = None):
         """num_slots > 1: trajectory layout -- every output tensor is allocated `[num_slots, B, ...]` (`self.traj`,
         `self.traj_reward`, ...), `select_slot(s)` chooses the slot the next reset / step writes and `self.obs`,
-        `self.reward`, `self.done`, `self.info_raw` are views of that slot (pcbenv_bind_buffers_slots)."""
+        `self.reward`, `self.done`, `self.info_raw` are views of that slot (pcbenv_bind_buffers_slots).
+        options: tuning knobs of the handle, `pcbenv_set_option` (include/pcbenv.h): "stream_threshold_bytes",
+        "terminal_teams", "gen_grid", "gen_lanes" -- none changes a result."""
         cfg.validate()
         self.cfg, self.num_envs, self.queue_depth = cfg, int(num_envs), int(queue_depth)
         self.run_seed, self.first_env_index = int(run_seed), int(first_env_index)
@@ -84,6 +86,8 @@ class BatchedPlacementEnv:
         dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         _lib.check(self._L.pcbenv_create(C.byref(self._ccfg), dev_index, C.byref(h)))
         self._h = h
+        for name, value in (options or {}).items():
+            self.set_option(name, value)
         B = self.num_envs
         S = self.num_slots = int(num_slots)
         with torch.cuda.device(self.device):
@@ -132,6 +136,11 @@ class BatchedPlacementEnv:
             self.close()
         except Exception:
             pass
+
+    def set_option(self, name: str, value: int):
+        code = {"stream_threshold_bytes": _lib.OPT_STREAM_THRESHOLD_BYTES, "terminal_teams": _lib.OPT_TERMINAL_TEAMS,
+                "gen_grid": _lib.OPT_GEN_GRID, "gen_lanes": _lib.OPT_GEN_LANES}[name]
+        _lib.check(self._L.pcbenv_set_option(self._h, code, int(value)), self._h)
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

@@ -25,7 +25,7 @@ def test_header_symbols_are_exported():
     for n in names:
         assert hasattr(L, n), f"libpcbenv.so does not export {n}"
     assert set(names) == set(_lib.EXPORTS), "pcbenv/_lib.py binds a different set than the header declares"
-    assert L.pcbenv_abi_version() == 2
+    assert L.pcbenv_abi_version() == _lib.ABI_VERSION == 3
 
 
 def test_sizes_match_host_packing():

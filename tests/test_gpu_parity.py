@@ -72,14 +72,16 @@ def test_golden_episodes_on_gpu(name):
 
 
 def _oracle_rollout(cfg, B, episodes, queue_depth=2, p_bad=0.02, incremental=False, auto_reset=False, fused=False,
-                    threads=0, cpu_threads=1, stats=None, max_steps=400, num_slots=1, device_instances=False):
+                    threads=0, cpu_threads=1, stats=None, max_steps=400, num_slots=1, device_instances=False, options=None,
+                    stagger=0):
     """Device-sampled legal actions (plus a few corrupted ones); every observation, reward, done, info of every step
     must equal the CPU oracle's.  Covers reset_done() and the instance queue.  cpu_threads > 1: the oracle steps and
     the whole-batch tensor comparison run under OpenMP (full-size batches).  stats: filled with counts of the
-    terminal kinds seen."""
+    terminal kinds seen.  stagger = L: during the first L steps environment i is reset once more after step
+    i % L, so that from then on 1 / L of the batch ends an episode in every launch (the loop a policy runs)."""
     from oracle import oracle as orc
     env = BatchedPlacementEnv(cfg, B, queue_depth=queue_depth, run_seed=3, incremental_obs=incremental,
-                              auto_reset=auto_reset, threads_per_env=threads, num_slots=num_slots)
+                              auto_reset=auto_reset, threads_per_env=threads, num_slots=num_slots, options=options)
     if device_instances:  # fresh instances from the on-device generator; the oracle takes the host generator's records
         from pcbenv.instances import NativeInstanceStreams
         env.enable_device_instances()
@@ -155,6 +157,10 @@ def _oracle_rollout(cfg, B, episodes, queue_depth=2, p_bad=0.02, incremental=Fal
         if not auto_reset:
             env.reset_done()
             oracle_reset(d)
+        if t < stagger:  # spread the episode phases: one more reset for a 1 / stagger slice of the batch
+            m = (np.arange(B) % stagger == t).astype(np.uint8)
+            env.reset(torch.from_numpy(m))
+            oracle_reset(m)
         steps += B
         t += 1
     if device_instances:
@@ -214,6 +220,31 @@ def test_auto_reset_and_fused_sampling(name):
 def test_auto_reset_with_beam_routes():
     _oracle_rollout(named_config("c4", "both"), 16, episodes=3, auto_reset=True, fused=True)
     _oracle_rollout(EnvConfig.pin(12, 12, 5, 5, 2, 5, 2, 5, 8, 6, 3, 5, 7, 2, "beam", 2, 0.25), 24, episodes=3, p_bad=0.05, auto_reset=True)
+
+
+@pytest.mark.parametrize("name,B,teams,fused", [("c3", 1024, None, False), ("c4", 512, None, False), ("c3", 1024, 3, True), ("c4", 256, 5, False),
+                                                 ("c2", 1024, None, True), ("c3_both", 512, None, False), ("mid_beam", 384, 7, False),
+                                                 ("c3", 1024, 0, False)])
+def test_terminal_teams_with_staggered_episodes(name, B, teams, fused):
+    """One launch per step, episode phases spread over the batch (1 / L of it terminal in every launch): the
+    environments on the terminal list run on four-wavefront teams of k_step_mixed, the others on one wavefront each --
+    every tensor of every environment at every step vs the oracle, with corrupted actions (terminal at once, off the
+    list), lists longer than the teams' capacity (teams = 3 / 5 / 7: the rest falls back to its own wavefront) and
+    the plain kernel (teams = 0)."""
+    cfg = {"c3_both": lambda: named_config("c3", "both"),
+           "mid_beam": lambda: EnvConfig.pin(12, 12, 5, 5, 2, 5, 2, 5, 8, 6, 3, 5, 7, 2, "beam", 2, 0.25)}.get(name, lambda: named_config(name))()
+    L = cfg.max_num_components
+    opts = None if teams is None else {"terminal_teams": teams}
+    stats = {}
+    _oracle_rollout(cfg, B, episodes=3, queue_depth=3, p_bad=0.0 if fused else 0.01, auto_reset=True, fused=fused, cpu_threads=16,
+                    stats=stats, max_steps=4 * L, options=opts, stagger=L)
+    if cfg.kind in (KIND_PIN, KIND_SPATIAL):
+        assert stats["routed_terminals"] >= B
+    # the explicit loop (step, then reset the finished ones): the terminal teams run reward-only terminal transitions
+    _oracle_rollout(cfg, min(B, 256), episodes=2, queue_depth=2, p_bad=0.01, auto_reset=False, cpu_threads=16, max_steps=3 * L, options=opts, stagger=L)
+    # trajectory layout
+    _oracle_rollout(cfg, min(B, 128), episodes=2, queue_depth=2, p_bad=0.01, auto_reset=True, cpu_threads=16, max_steps=3 * L, options=opts, stagger=L,
+                    num_slots=5)
 
 
 @pytest.mark.parametrize("threads", [64, 256])
@@ -382,7 +413,8 @@ def test_full_size_batches(name, B):
         a.step(act)
         _, _, _, _, act_b = b.rollout_step(t)
         assert torch.equal(act, act_b), t
-        assert torch.equal(a.reward, b.reward) and torch.equal(a.done, b.done), t
+        bad = ((a.reward != b.reward) | (a.done != b.done)).nonzero().flatten()
+        assert len(bad) == 0, (t, len(bad), bad[:8].tolist(), a.reward[bad[:4]].tolist(), b.reward[bad[:4]].tolist(), a.done[bad[:4]].tolist(), b.done[bad[:4]].tolist())
         feat = a.obs["all_components_feature"]
         placed = (feat[:, :, 2] >= 0).double()
         area = (feat[:, :, 0] * feat[:, :, 1] * placed).sum(dim=1)
@@ -423,12 +455,11 @@ def test_every_tensor_at_the_baseline_batches(name, B, stream_mb, monkeypatch):
     sampling + in-launch reset): EVERY observation tensor, reward, done and info of EVERY environment at every step
     against the CPU oracle.  stream_mb forces the other store flavour (0: streaming `sc1 nt` stores below the
     Infinity-Cache threshold; 1 << 20: write-through `sc1` stores for a c5 batch that would otherwise stream)."""
-    if stream_mb is not None:
-        monkeypatch.setenv("PCBENV_STREAM_THRESHOLD_MB", str(stream_mb))
     cfg = named_config(name)
     stats = {}
     n = _oracle_rollout(cfg, B, episodes=1, queue_depth=2, p_bad=0.0, auto_reset=True, fused=True, cpu_threads=16,
-                        stats=stats, max_steps=cfg.max_num_components + 2)
+                        stats=stats, max_steps=cfg.max_num_components + 2,
+                        options=None if stream_mb is None else {"stream_threshold_bytes": stream_mb << 20})
     assert n >= B * cfg.max_num_components
     if cfg.kind in (KIND_PIN, KIND_SPATIAL):
         assert stats["routed_terminals"] >= B
@@ -539,11 +570,10 @@ def test_device_instance_generator_equals_the_host_streams(name, B, lanes, monke
     test_instance_gen_native.py and the golden tables): the whole queue after enabling, and -- after rollouts that
     consume and refill it several times over -- every record an environment is about to take."""
     from pcbenv.instances import NativeInstanceStreams
-    if lanes:  # lanes per environment of the generator kernel (default: the narrowest group the configuration allows)
-        monkeypatch.setenv("PCBENV_GEN_LANES", str(lanes))
     cfg = GEN_CASES[name]()
     Q = 8
-    env = BatchedPlacementEnv(cfg, B, queue_depth=Q, run_seed=7, auto_reset=True)
+    # lanes per environment of the generator kernel (default: the narrowest group the configuration allows)
+    env = BatchedPlacementEnv(cfg, B, queue_depth=Q, run_seed=7, auto_reset=True, options={"gen_lanes": lanes} if lanes else None)
     env.enable_device_instances()
     host = NativeInstanceStreams(cfg, [env_seed(7, i) for i in range(B)])
     K = 80
@@ -756,7 +786,8 @@ def test_step_is_graph_capturable_with_a_policy():
         g.replay()
         torch.cuda.synchronize()
         assert torch.equal(acts_a, acts_b), t
-        assert torch.equal(a.reward, b.reward) and torch.equal(a.done, b.done), t
+        bad = ((a.reward != b.reward) | (a.done != b.done)).nonzero().flatten()
+        assert len(bad) == 0, (t, len(bad), bad[:8].tolist(), a.reward[bad[:4]].tolist(), b.reward[bad[:4]].tolist(), a.done[bad[:4]].tolist(), b.done[bad[:4]].tolist())
         for k in a.obs:
             assert torch.equal(a.obs[k], b.obs[k]), (t, k)
     a.close(); b.close()

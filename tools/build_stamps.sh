@@ -4,7 +4,4 @@
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p stamps_tmp
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared -std=c++17 -Wno-unused-value -pthread \
-  -DPCBENV_STAMPS "$@" -Iinclude -o ${STAMPS_OUT:-stamps_tmp/libpcbenv_stamps.so} \
-  rl-environment-for-component-placement_amd/csrc/pcbenv_kernels.hip rl-environment-for-component-placement_amd/csrc/instance_gen.cpp
-echo stamps_tmp/libpcbenv_stamps.so
+python rl-environment-for-component-placement_amd/build.py -DPCBENV_STAMPS "$@" ${STAMPS_OUT:-stamps_tmp/libpcbenv_stamps.so} | tail -n1

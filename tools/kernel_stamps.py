@@ -19,6 +19,7 @@ from pcbenv.batched_env import BatchedPlacementEnv  # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else "c3"
 reward = sys.argv[3] if len(sys.argv) > 3 else "centroid"
+opts = {"terminal_teams": int(sys.argv[4])} if len(sys.argv) > 4 else None  # 0 = plain k_step, omitted = the default
 cfg = named_config(name, reward)
 B, L = int(sys.argv[2]) if len(sys.argv) > 2 else 4096, cfg.max_num_components
 TERM = [("load", 0, 1), ("sample", 1, 2), ("update", 2, 3), ("fold+emit", 3, 4), ("reward:offsets+centroids", 4, 5),
@@ -58,7 +59,7 @@ def report(title, s, done):
 
 
 for stagger in (False, True):
-    env = BatchedPlacementEnv(cfg, B, queue_depth=2, auto_reset=True)
+    env = BatchedPlacementEnv(cfg, B, queue_depth=2, auto_reset=True, options=opts)
     env.generate_instances(); env.reset()
     env._L.pcbenv_debug_stamps.argtypes = [C.c_void_p, C.c_void_p]
     acts = torch.empty((B, 3), dtype=torch.int32, device="cuda")

@@ -470,7 +470,7 @@ static __device__ __forceinline__ void beam_routes(const SegView &v, const EnvHd
     const int np = hdr->npins, nn = hdr->nnets;
     for (int q = lane; q < np; q += NT) {  // distance of every pin to its net's centroid (v.D is free until the segments are written)
         const PinRec pr = pins[q];
-        v.D[q] = norm2((double)pr.abs_x - v.cen[pr.net], (double)pr.abs_y - v.cen[PCBENV_MAX_NETS + pr.net]);
+        v.D[q] = norm2((double)pr.abs_x - v.cen[pr.net], (double)pr.abs_y - v.cen[v.N + pr.net]);
     }
     lds_sync();
     // workgroup-uniform: the widest net of this instance decides which build runs (every wavefront looks at all nets)
@@ -498,7 +498,7 @@ static __device__ __forceinline__ void beam_routes(const SegView &v, const EnvHd
 // (S:609-627 lowest_num_intersections) once the shares of all teams are in.
 static __device__ __forceinline__ void route_beam_or_both(const DevParams &p, const EnvHdr *hdr, const PinRec *pins, double *seg,
                                           int lane, int part, int nparts, double *wl, int *ni) {
-    const SegView v = seg_view(seg, p.P);
+    const SegView v = seg_view(seg, p.P, p.N);
     unsigned char *beam = v.beam;
     net_offsets_and_centroids(v, hdr, pins, lane);
     STAMP(5);

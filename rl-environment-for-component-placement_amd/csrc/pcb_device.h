@@ -29,6 +29,7 @@ struct DevParams {
     long long stateStride, instStride;
     int offOcc, offVm, offComps, offPins, offRank;   // byte offsets inside a state block
     int ldsHf, ldsCls, ldsSeg, ldsBytes;    // byte offsets of LDS scratch behind the state mirror
+    int ldsHfWords;                         // 64-bit words of the fold scratch / row-membership bit map at ldsHf (sized by need)
     unsigned char *state, *queue;
     pcbenv_buffers buf;
     unsigned long long *dbg;                // diagnostic build only (-DPCBENV_STAMPS): [B][32] s_memtime stamps
@@ -47,17 +48,17 @@ struct DevParams {
     // another stream (k_gen_fill) may run on any XCD, whose L2 is not coherent with the writer's.
     unsigned *cursor_pub;
     // Terminal list (Team<>::run_env has the story): `seq` numbers the step launches of this handle; launch seq starts
-    // term_hpe helper teams per entry of ring seq & 3 (term_wgs = term_cap entries' worth of workgroups behind the
-    // environments' own, when the launch has helpers at all), appends to ring (seq + 1) & 3 and clears the counters of ring
-    // (seq + 2) & 3.  A ring is TERM_SHARDS shards of term_cap / TERM_SHARDS entries, each with a counter on a line of its
-    // own (term_cnt[(ring * TERM_SHARDS + shard) * TERM_CNT_STRIDE]); entry (shard, idx) sits at shard * cps + idx.
-    // term_cap == 0: no lists are kept; term_wgs == 0: this launch has no helpers (marks are ignored).
+    // REWARD_PARTS helper teams for each of the first term_wgs entries of ring seq & 3, appends to ring (seq + 1) & 3 and
+    // clears the counters of ring (seq + 2) & 3.  A ring is TERM_SHARDS shards of term_cap / TERM_SHARDS entries, each with
+    // a counter on a line of its own (term_cnt[(ring * TERM_SHARDS + shard) * TERM_CNT_STRIDE]); entry (shard, idx) has
+    // the number idx * TERM_SHARDS + shard.  term_cap == 0: no lists are kept; term_wgs == 0: this launch has no helpers.
     unsigned seq;
-    int term_wgs, term_cap, term_hpe;
+    int term_wgs, term_cap, term_hpe;  // term_hpe = helper teams per entry: REWARD_PARTS, + 1 feature helper with PCBENV_FLAG_AUTO_RESET
     int *term_list;
     unsigned *term_cnt;
     u64 *term_mark;    // [2][B]: (launch number << 32 | list position) of environment e for launches of that parity
     u64 *term_arrive;  // [term_cap]: where the shares of a routing reward meet (terminal_reward)
+    unsigned *term_seen;  // host memory: the longest shard of the latest launch's list (sizes later helper grids)
     unsigned char *state_out;  // the state blocks this launch writes (p.state: the ones it reads); equal for in-place kernels
 };
 // Loads of data another stream's kernel (or a DMA) has written since this XCD last read the same addresses: instance

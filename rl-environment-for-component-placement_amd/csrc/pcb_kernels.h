@@ -23,11 +23,15 @@ __global__ __launch_bounds__(64 * NW) void k_reset(DevParams p, const unsigned c
     T::store_state(smem, p, e, lane);
 }
 
-// The step kernel, one team of NW wavefronts per workgroup (Team<>::run_env has the story).  Workgroups [0, B) are the
-// environments' own teams; a launch with helpers (p.term_wgs > 0: one transition per launch, one-wavefront teams) has
-// term_wgs * term_hpe more behind them, the reward helpers of the terminal list: workgroup B + (k * term_hpe + part)
-// serves the k-th entry in idx-major order (k = idx * TERM_SHARDS + shard, so that the occupied entries -- the low idx
-// of every shard -- come first and start first); unused ones look at their shard's counter and leave.
+// The step kernel, one team of NW wavefronts per workgroup (Team<>::run_env has the story).  A launch with helpers
+// (p.term_wgs > 0: one transition per launch, one-wavefront teams, pin kinds) starts with term_wgs * term_hpe
+// helpers -- workgroup k * term_hpe + part serves entry k of the terminal list, entries being numbered idx *
+// TERM_SHARDS + shard so that the occupied ones (the low idx of every shard) come first; unused ones look at their
+// shard's counter and leave -- followed by the B environments' own teams.  The helpers come FIRST so that they hold a
+// slot from the first cycle of the launch (behind 4 096 environments' workgroups the last of them found none until the
+// first environments had finished, 14 us into a 20 us launch), and there are only as many as the lists have lately been
+// long: the first environment workgroup reports this launch's longest shard to host memory, pcbenv_step* sizes the next
+// helper grids from it (an environment is only delegated if its entry's helpers were started).
 // Four wavefronts per SIMD (16 one-wavefront workgroups per CU) is all a launch of up to ~4 workgroups per SIMD needs and
 // what LDS allows anyway; holding the lean build to 72 VGPRs for 7 wavefronts (spills inside the routing reward and one
 // at entry) measured 2-5 % slower at every batch size, so both builds may use up to 128.
@@ -39,20 +43,27 @@ __global__ __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(64 * NW)
     const int num_steps = TRAJ ? num_steps_ : 1;
     // above the generator's wavefronts (priority 0) when both share a SIMD: the step kernel is the latency-critical one
     __builtin_amdgcn_s_setprio(3);
-    if (p.term_cap > 0 && blockIdx.x == 0 && threadIdx.x < TERM_SHARDS)  // the ring after next starts empty
-        store_agent(p.term_cnt + ((((p.seq + 2u) & 3u) * TERM_SHARDS + threadIdx.x) * TERM_CNT_STRIDE), 0u);
-    int e = blockIdx.x, role = ROLE_ENV, part = 0;
+    constexpr bool HELPERS = NW == 1 && (KIND == PCBENV_PIN || KIND == PCBENV_SPATIAL);
+    const int nh = HELPERS ? p.term_wgs * p.term_hpe : 0;  // helper workgroups at the head of the grid
+    int e = (int)blockIdx.x - nh, role = ROLE_ENV, part = 0;
     unsigned pos = 0u;
-    if (NW == 1 && (KIND == PCBENV_PIN || KIND == PCBENV_SPATIAL) && (int)blockIdx.x >= p.B) {  // a reward helper (only launched with p.term_wgs > 0)
-        const unsigned hb = blockIdx.x - (unsigned)p.B, hpe = (unsigned)p.term_hpe, k = hb / hpe;
+    if (HELPERS && e < 0) {  // a reward helper
+        const unsigned hb = blockIdx.x, hpe = (unsigned)p.term_hpe, k = hb / hpe;  // hpe = REWARD_PARTS (+ 1: the feature helper)
         part = (int)(hb - k * hpe);
         const unsigned ring = p.seq & 3u, cps = (unsigned)p.term_cap / TERM_SHARDS, shard = k & (TERM_SHARDS - 1u), idx = k >> TERM_SHARD_BITS;
         const unsigned cnt = (unsigned)__builtin_amdgcn_readfirstlane((int)load_agent(p.term_cnt + (ring * TERM_SHARDS + shard) * TERM_CNT_STRIDE));
         if (idx >= cps || idx >= cnt) return;
-        pos = shard * cps + idx;
+        pos = k;
         // (wave-uniform values the compiler cannot see as such: kept in scalar registers, like blockIdx.x)
         e = __builtin_amdgcn_readfirstlane(p.term_list[ring * (unsigned)p.term_cap + pos]);
-        role = ROLE_REWARD;
+        role = part < REWARD_PARTS ? ROLE_REWARD : ROLE_FEATURES;
+    } else if (p.term_cap > 0 && e == 0 && threadIdx.x < TERM_SHARDS) {
+        // list bookkeeping, by the first environment workgroup: the ring after next starts empty, and the host learns how
+        // long this launch's shards are (any later launch may read it, whenever: it only sizes helper grids)
+        store_agent(p.term_cnt + ((((p.seq + 2u) & 3u) * TERM_SHARDS + threadIdx.x) * TERM_CNT_STRIDE), 0u);
+        unsigned longest = load_agent(p.term_cnt + (((p.seq & 3u) * TERM_SHARDS + threadIdx.x) * TERM_CNT_STRIDE));
+        for (int o = TERM_SHARDS / 2; o > 0; o >>= 1) longest = max(longest, (unsigned)__shfl_xor((int)longest, o, TERM_SHARDS));
+        if (threadIdx.x == 0) __hip_atomic_store(p.term_seen, longest, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     Team<64 * NW>::template run_env<KIND, WW, ROUTES, TRAJ>(p, smem, e, threadIdx.x, actions, fmt, sampled, seed, first_env, step_index,
                                                            num_steps, role, part, pos);

@@ -265,8 +265,9 @@ template <int KIND> static __device__ inline void emit_features_full(const DevPa
     if (p.buf.all_components_feature) {
         const PinTables t = pin_tables(p, l);
         double *cf = p.buf.all_components_feature + (size_t)row * p.C * p.F;
+        int c = lane / p.F, k = lane - c * p.F;  // (component, field) advanced without a division per element
+        const int dc = NT / p.F, dk = NT - dc * p.F;
         for (int i = lane; i < p.C * p.F; i += NT) {
-            const int c = i / p.F, k = i - c * p.F;
             double v = 0.0;
             if (c < nc) {
                 const CompRec cr = l.comps[c];
@@ -278,6 +279,8 @@ template <int KIND> static __device__ inline void emit_features_full(const DevPa
                 }
             }
             cf[i] = v;
+            c += dc; k += dk;
+            if (k >= p.F) { k -= p.F; c++; }
         }
     }
     if (p.buf.placement_mask) {
@@ -306,10 +309,10 @@ template <int KIND> static __device__ inline void emit_features_full(const DevPa
                 if (fn) { fn[4 * r] = pr.rel_x; fn[4 * r + 1] = pr.rel_y; fn[4 * r + 2] = pr.abs_x; fn[4 * r + 3] = pr.abs_y; }
                 if (fc) { fc[2 * r] = pr.net; fc[2 * r + 1] = pr.comp; }
             }
-        } else if (p.pinRows <= p.H * p.WW * 64) {  // pin env: rows [component, pin_id] through a membership bit map
+        } else if (p.pinRows <= p.ldsHfWords * 64) {  // pin env: rows [component, pin_id] through a membership bit map
             u64 *rowbits = l.hf;
             lds_sync();
-            for (int i = lane; i < p.H * p.WW; i += NT) rowbits[i] = 0ull;
+            for (int i = lane; i < p.ldsHfWords; i += NT) rowbits[i] = 0ull;
             lds_sync();
             for (int q = lane; q < np; q += NT) {
                 const PinRec pr = l.pins[q];

@@ -18,8 +18,16 @@ static __device__ inline void fetch_instance(const DevParams &p, unsigned qcurso
     for (int r = 0; r < 4; r++) { const int q = lane + r * NT; ir.pin[r] = q < p.P ? load_agent(prec + q) : 0ull; }
 }
 
-template <int KIND, int WW, bool TRAJ> static __device__ inline void reset_env(const DevParams &p, Lds &l, int e, int row, int lane) {
+// `what`: RESET_ALL, or the two halves a delegated reset is split into (run_env): RESET_STATE_MASKS = the new episode's
+// state in LDS (for the state block) + grid and action_mask, by the environment's own team; RESET_FEATURES = everything
+// else the reset writes (feature tensors, pin_grid, component_grid), by a helper team working from its own copy of the
+// old state and the same queued instance.  The two write disjoint tensors.
+#define RESET_STATE_MASKS 1
+#define RESET_FEATURES 2
+#define RESET_ALL 3
+template <int KIND, int WW, bool TRAJ> static __device__ inline void reset_env(const DevParams &p, Lds &l, int e, int row, int lane, int what = RESET_ALL) {
     const int H = p.H, W = p.W, HW = H * W;
+    const bool owner = what & RESET_STATE_MASKS, feats = what & RESET_FEATURES;
     const bool full = TRAJ && p.num_slots > 1;  // trajectory layout: the destination slot holds nothing of this environment yet
     lds_sync();
     // The float64 pin-feature tensors are maintained row-wise (a step rewrites only the placed component's
@@ -31,14 +39,14 @@ template <int KIND, int WW, bool TRAJ> static __device__ inline void reset_env(c
     InstRegs ir;
     if (KIND != PCBENV_SQUARE) {
         fetch_instance(p, l.hdr->qcursor, e, lane, ir);
-        if (p.gen_produced && lane == 0 && load_agent(p.gen_produced + e) <= l.hdr->qcursor) atomicOr(p.gen_errors, 1u);
+        if (owner && p.gen_produced && lane == 0 && load_agent(p.gen_produced + e) <= l.hdr->qcursor) atomicOr(p.gen_errors, 1u);
     }
     bool rows_cleared = false;
-    if ((KIND == PCBENV_PIN || KIND == PCBENV_SPATIAL) && !full && l.hdr->feat_gen == p.bind_gen &&
-        (KIND == PCBENV_SPATIAL || p.C * p.mp <= H * WW * 64)) {
+    if (feats && (KIND == PCBENV_PIN || KIND == PCBENV_SPATIAL) && !full && l.hdr->feat_gen == p.bind_gen &&
+        (KIND == PCBENV_SPATIAL || p.C * p.mp <= p.ldsHfWords * 64)) {
         u64 *rowbits = l.hf;
         if (KIND == PCBENV_PIN) {
-            for (int i = lane; i < H * WW; i += NT) rowbits[i] = 0ull;
+            for (int i = lane; i < p.ldsHfWords; i += NT) rowbits[i] = 0ull;
             lds_sync();
             #pragma unroll
             for (int r = 0; r < 4; r++) {
@@ -91,7 +99,7 @@ template <int KIND, int WW, bool TRAJ> static __device__ inline void reset_env(c
         if (lane == 0) {
             l.hdr->ncomp = (short)nc; l.hdr->nnets = (short)nn; l.hdr->npins = (short)np; l.hdr->cur = 0;
             l.hdr->qcursor += 1; l.hdr->episode += 1;
-            store_agent(p.cursor_pub + e, l.hdr->qcursor);
+            if (owner) store_agent(p.cursor_pub + e, l.hdr->qcursor);
         }
         lds_sync();
         if (KIND == PCBENV_PIN && lane < WAVE) {
@@ -138,31 +146,48 @@ template <int KIND, int WW, bool TRAJ> static __device__ inline void reset_env(c
     }
     lds_sync();
     STAMP(16);
-    mask_and_emit<KIND, WW>(p, l, row, lane, true, 0, H);
+    if (owner) mask_and_emit<KIND, WW>(p, l, row, lane, true, 0, H);
     STAMP(17);
 
     if (KIND != PCBENV_SQUARE) {
         const int nc = l.hdr->ncomp, np = l.hdr->npins;
         if (KIND == PCBENV_SPATIAL) {
             // rank of every pin among the pins of its component (self.pins order), kept in the state block
-            for (int q = lane; q < np; q += NT) {
-                const int comp = l.pins[q].comp;
-                int rank = 0;
-                #pragma unroll 4
-                for (int q2 = 0; q2 < np; q2++) rank += (q2 < q) & (l.pins[q2].comp == comp);  // broadcast reads
-                l.rank[q] = (unsigned char)rank;
+            if (np <= WAVE) {  // one pin per lane of wavefront 0: one ballot per component instead of np broadcast reads per pin
+                if (lane < WAVE) {
+                    const int comp = lane < np ? (int)l.pins[lane].comp : -1;
+                    int rank = 0;
+                    for (int c = 0; c < nc; c++) {
+                        const u64 m = __ballot(comp == c);
+                        if (comp == c) rank = __popcll(m & ((1ull << lane) - 1ull));
+                    }
+                    if (lane < np) l.rank[lane] = (unsigned char)rank;
+                }
+            } else {
+                for (int q = lane; q < np; q += NT) {
+                    const int comp = l.pins[q].comp;
+                    int rank = 0;
+                    #pragma unroll 4
+                    for (int q2 = 0; q2 < np; q2++) rank += (q2 < q) & (l.pins[q2].comp == comp);  // broadcast reads
+                    l.rank[q] = (unsigned char)rank;
+                }
             }
-            build_pin_tables(p, l, lane);  // pid / netmask scratch in the class-map zone (free until the next emit_pin_grid)
+            if (feats) build_pin_tables(p, l, lane);  // pid / netmask scratch in the class-map zone (free until the next emit_pin_grid)
         }
-        if (full) {
+        if ((KIND == PCBENV_PIN || KIND == PCBENV_SPATIAL) && lane == 0) l.hdr->feat_gen = p.bind_gen;  // (state: whoever fills the rows, they are filled)
+        if (!feats) {
+            // the feature tensors, pin_grid and component_grid are the helper's
+        } else if (full) {
             emit_features_full<KIND>(p, l, row, lane);
         } else {
             const PinTables t = pin_tables(p, l);
             // all_components_feature (R:60-79, S:203-239): [h, w, -1, -1, area/(H*W), (spatial: pin ids, -1 pad)]; absent rows 0
             if (p.buf.all_components_feature) {
                 double *cf = p.buf.all_components_feature + (size_t)row * p.C * p.F;
+                // one (component, field) element per lane and trip, the pair advanced without a division per element
+                int c = lane / p.F, k = lane - c * p.F;
+                const int dc = NT / p.F, dk = NT - dc * p.F;
                 for (int i = lane; i < p.C * p.F; i += NT) {
-                    const int c = i / p.F, k = i - c * p.F;
                     double v = 0.0;
                     if (c < nc) {
                         const CompRec cr = l.comps[c];
@@ -174,6 +199,8 @@ template <int KIND, int WW, bool TRAJ> static __device__ inline void reset_env(c
                         }
                     }
                     cf[i] = v;
+                    c += dc; k += dk;
+                    if (k >= p.F) { k -= p.F; c++; }
                 }
             }
             STAMP(18);
@@ -196,7 +223,6 @@ template <int KIND, int WW, bool TRAJ> static __device__ inline void reset_env(c
                     for (int i = lane; i < p.pinRows * p.catW; i += NT)
                         f[i] = (KIND == PCBENV_SPATIAL && i >= (p.pinRows - 1) * p.catW) ? -1.0 : 0.0;  // S:1520
                 }
-                if (lane == 0) l.hdr->feat_gen = p.bind_gen;
                 if (!rows_cleared) {  // first reset after a bind: the full zero fill above must land before the row writes
                     store_drain_sync();
                     __threadfence_block();
@@ -216,7 +242,7 @@ template <int KIND, int WW, bool TRAJ> static __device__ inline void reset_env(c
             }
         }
         STAMP(19);
-        if (KIND == PCBENV_SPATIAL) {
+        if (KIND == PCBENV_SPATIAL && feats) {
             if (p.buf.pin_grid) emit_zero(p.buf.pin_grid + (size_t)row * HW * p.K, (long long)HW * p.K, lane, p.stream_stores);  // S:1504
             emit_component_grid(p, l, row, lane);  // S:1677-1697 draw_components (unrotated rel coords; channel 0 == 1)
         }

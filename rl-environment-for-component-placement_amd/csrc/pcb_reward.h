@@ -22,24 +22,28 @@ static __device__ inline bool is_intersect(double x1, double y1, double x2, doub
 // ---- routes -------------------------------------------------------------------------------------
 // A route is kept as one segment slot per pin q (slots of net n are nstart[n]..nstart[n+1]-1, so slots are
 // net-major like the reference's route lists); act[q] = 1 if the slot carries a segment.
-struct SegView { double *X1, *Y1, *X2, *Y2, *D, *A, *DX, *DY, *cen; int *act, *nstart, *nsum; unsigned *bbox; unsigned short *pairs; unsigned char *beam; };
+struct SegView { double *X1, *Y1, *X2, *Y2, *D, *A, *DX, *DY, *cen; int *act, *nstart, *nsum; unsigned *bbox; unsigned short *pairs; unsigned char *beam; int N; };  // N = max_num_nets: the per-net tables' size
 // compaction buffer of candidate (i, j) pairs, per wavefront: a dense batch is two candidates per lane (128), a
 // sweep step appends at most 4 * 64 to a partial batch (< 128), and what does not fill a batch is moved to the front
 #define PAIR_ENTRIES_PER_WAVE 384
 // [segments X1 Y1 X2 Y2 D | centroids | act nstart total nsum] then a zone used only by the pair count
 // (A DX DY bbox pairs), which the beam search -- finished before the count starts -- overlays with its per-net scratch.
-#define SEG_INTS(P) ((P) + (PCBENV_MAX_NETS + 1) + 3 + 2 * PCBENV_MAX_NETS)
-#define SEG_FIXED_BYTES(P) ((5 * (P) + 2 * PCBENV_MAX_NETS) * 8 + SEG_INTS(P) * 4)
+// (the per-net tables are sized by the configuration's max_num_nets N, not by PCBENV_MAX_NETS: at c3 / c4 that and a fold
+// scratch sized by need bring a workgroup's LDS from 7.8 to 6.6 KB -- 24 instead of 20 one-wavefront workgroups per CU,
+// the headroom the reward helpers start in)
+#define SEG_INTS(P, N) ((P) + ((N) + 1) + 3 + 2 * (N))
+#define SEG_FIXED_BYTES(P, N) ((5 * (P) + 2 * (N)) * 8 + SEG_INTS(P, N) * 4)
 #define SEG_COUNT_BYTES(P, NW) (3 * (P) * 8 + (P) * 4 + PAIR_ENTRIES_PER_WAVE * 2 * (NW))
-#define SEG_LDS_BYTES(P, NW, beam) (((SEG_FIXED_BYTES(P) + 7) & ~7) + ((beam) > SEG_COUNT_BYTES(P, NW) ? (beam) : SEG_COUNT_BYTES(P, NW)))
-static __device__ inline SegView seg_view(double *seg, int P) {
+#define SEG_LDS_BYTES(P, N, NW, beam) (((SEG_FIXED_BYTES(P, N) + 7) & ~7) + ((beam) > SEG_COUNT_BYTES(P, NW) ? (beam) : SEG_COUNT_BYTES(P, NW)))
+static __device__ inline SegView seg_view(double *seg, int P, int N) {
     SegView v;
+    v.N = N;
     v.X1 = seg; v.Y1 = seg + P; v.X2 = seg + 2 * P; v.Y2 = seg + 3 * P; v.D = seg + 4 * P;
-    v.cen = seg + 5 * P;                              // cx[MAX_NETS], cy[MAX_NETS]
-    v.act = (int *)(v.cen + 2 * PCBENV_MAX_NETS);     // [P]
-    v.nstart = v.act + P;                             // [MAX_NETS + 1], then 3 spare words (nstart[MAX_NETS + 1] = pair counter)
-    v.nsum = v.nstart + PCBENV_MAX_NETS + 1 + 3;      // [2 * MAX_NETS] integer coordinate sums per net
-    v.beam = (unsigned char *)seg + ((SEG_FIXED_BYTES(P) + 7) & ~7);
+    v.cen = seg + 5 * P;                              // cx[N], cy[N]
+    v.act = (int *)(v.cen + 2 * N);                   // [P]
+    v.nstart = v.act + P;                             // [N + 1], then 3 spare words (nstart[N + 1] = pair counter)
+    v.nsum = v.nstart + N + 1 + 3;                    // [2 * N] integer coordinate sums per net
+    v.beam = (unsigned char *)seg + ((SEG_FIXED_BYTES(P, N) + 7) & ~7);
     v.A = (double *)v.beam; v.DX = v.A + P; v.DY = v.A + 2 * P;  // per segment: x1*y2 - y1*x2, x1 - x2, y1 - y2
     v.bbox = (unsigned *)(v.A + 3 * P);               // [P] integer extents (x_lo, x_hi, y_lo, y_hi), one byte each
     v.pairs = (unsigned short *)(v.bbox + P);         // [PAIR_ENTRIES_PER_WAVE] per wavefront
@@ -51,20 +55,20 @@ static __device__ inline SegView seg_view(double *seg, int P) {
 static __device__ inline void net_offsets_and_centroids(const SegView &v, const EnvHdr *hdr, const PinRec *pins, int lane) {
     const int np = hdr->npins, nn = hdr->nnets;
     lds_sync();  // the segment area aliases the class map of emit_pin_grid
-    for (int n = lane; n < 2 * PCBENV_MAX_NETS; n += NT) v.nsum[n] = 0;
+    for (int n = lane; n < 2 * v.N; n += NT) v.nsum[n] = 0;
     lds_sync();
     for (int q = lane; q < np; q += NT) {
         const PinRec pr = pins[q];
         if (q == 0 || pr.net != pins[q - 1].net) v.nstart[pr.net] = q;
         atomicAdd(&v.nsum[pr.net], (int)pr.abs_x);
-        atomicAdd(&v.nsum[PCBENV_MAX_NETS + pr.net], (int)pr.abs_y);
+        atomicAdd(&v.nsum[v.N + pr.net], (int)pr.abs_y);
     }
     if (lane == 0) v.nstart[nn] = np;
     lds_sync();
     for (int n = lane; n < nn; n += NT) {
         const double cnt = (double)(v.nstart[n + 1] - v.nstart[n]);
         v.cen[n] = (double)v.nsum[n] / cnt;
-        v.cen[PCBENV_MAX_NETS + n] = (double)v.nsum[PCBENV_MAX_NETS + n] / cnt;
+        v.cen[v.N + n] = (double)v.nsum[v.N + n] / cnt;
     }
     lds_sync();
 }
@@ -77,7 +81,7 @@ static __device__ inline void build_centroid_segments(const SegView &v, const En
         double x1 = pins[q].abs_x, y1 = pins[q].abs_y, x2, y2;
         int a = 1;
         if (cnt == 2) { a = (q == s); x2 = pins[s + 1].abs_x; y2 = pins[s + 1].abs_y; }
-        else { x2 = v.cen[n]; y2 = v.cen[PCBENV_MAX_NETS + n]; }
+        else { x2 = v.cen[n]; y2 = v.cen[v.N + n]; }
         v.X1[q] = x1; v.Y1[q] = y1; v.X2[q] = x2; v.Y2[q] = y2; v.act[q] = a;
         v.D[q] = norm2(x1 - x2, y1 - y2);
     }
@@ -144,7 +148,7 @@ static __device__ inline int count_candidates(const SegView &v, const volatile l
 // with the reference's python float loop).
 // count_prepare reads the pins, count_finish only the segment zone.
 static __device__ inline void count_prepare(const SegView &v, int np, int lane) {
-    int *total_cnt = v.nstart + PCBENV_MAX_NETS + 1;  // spare slot behind nstart[0..MAX_NETS]
+    int *total_cnt = v.nstart + v.N + 1;  // spare slot behind nstart[0..MAX_NETS]
     for (int q = lane; q < np; q += NT) {
         const double x1 = v.X1[q], y1 = v.Y1[q], x2 = v.X2[q], y2 = v.Y2[q];
         v.A[q] = x1 * y2 - y1 * x2; v.DX[q] = x1 - x2; v.DY[q] = y1 - y2;
@@ -156,7 +160,7 @@ static __device__ inline void count_prepare(const SegView &v, int np, int lane) 
 // (part, nparts): the sweep steps are dealt to `nparts` teams of a launch (the environment's own wavefront and its reward
 // helpers, see run_env), this team being number `part`; *nintersections is then this team's share of the count.
 static __device__ inline void count_finish(const DevParams &p, const SegView &v, int np_, int nn_, int lane, int part, int nparts, double *wirelength, int *nintersections) {
-    int *total_cnt = v.nstart + PCBENV_MAX_NETS + 1;
+    int *total_cnt = v.nstart + v.N + 1;
     const int np = __builtin_amdgcn_readfirstlane(np_), nn = __builtin_amdgcn_readfirstlane(nn_);
     STAMP(12);
 #ifndef PCBENV_STAMPS_BEAM
@@ -242,7 +246,7 @@ static __device__ inline void count_and_length(const DevParams &p, const SegView
 
 static __device__ inline void route_centroid(const DevParams &p, const EnvHdr *hdr, const PinRec *pins, double *seg,
                                       int lane, int part, int nparts, double *wirelength, int *nintersections) {
-    const SegView v = seg_view(seg, p.P);
+    const SegView v = seg_view(seg, p.P, p.N);
     net_offsets_and_centroids(v, hdr, pins, lane);
     STAMP(5);
     build_centroid_segments(v, hdr, pins, lane);

@@ -28,13 +28,18 @@ static __device__ inline void presample_next(const DevParams &p, Lds &l, int sam
 //                   transition, the reset that follows (PCBENV_FLAG_AUTO_RESET), the state block -- and the worst-case
 //                   reward if the action turns out invalid (the helpers then leave);
 //   MODE_REWARD     a reward helper: replays the placement of the last component's pins in its own LDS copy of the state
-//                   and counts its part of the segment pairs; writes nothing but (if its share arrives last) reward and info.
+//                   and counts its part of the segment pairs; writes nothing but (if its share arrives last) reward and info;
+//   MODE_FEATURES   the feature helper (PCBENV_FLAG_AUTO_RESET only: the reset is then as certain as the end of the
+//                   episode): writes the half of the reset's observations that the environment's own team leaves out --
+//                   feature tensors, pin_grid, component_grid (reset_env's RESET_FEATURES) -- from its own copy of the old
+//                   state and the same queued instance.
 // Every team derives what happens (valid action or not, last component or not) from the same state block and the same
 // action, so they agree without talking to each other; only the environment's own team ever writes its state block.
 #define MODE_ALL 0
 #define MODE_DELEGATED 1
 #define MODE_REWARD 2
-#define REWARD_PARTS 3  // reward helpers per listed environment
+#define MODE_FEATURES 3
+#define REWARD_PARTS 2  // reward helpers per listed environment (+ one feature helper with PCBENV_FLAG_AUTO_RESET)
 
 // One transition of environment e with action (o, x, y): validate_action, update_grid, place_component, features,
 // legal mask + observation stream, done, terminal reward, and -- PCBENV_FLAG_AUTO_RESET -- the reset that follows a
@@ -43,6 +48,7 @@ template <int KIND, int WW, bool ROUTES, bool TRAJ>
 static __device__ __forceinline__ void transition(const DevParams &p, Lds &l, int e, int row, int lane, int o, int x, int y, int mode, int part, unsigned pos) {
     const int H = p.H, W = p.W, plane = H * WW;
     const bool auto_reset = p.flags & PCBENV_FLAG_AUTO_RESET;
+    if (mode == MODE_FEATURES) { reset_env<KIND, WW, TRAJ>(p, l, e, row, lane, RESET_FEATURES); return; }
     const bool full = TRAJ && p.num_slots > 1;  // trajectory layout: every tensor of the destination slot is written whole
     const int cur = l.hdr->cur, ncomp = l.hdr->ncomp, npins = l.hdr->npins;
     // validate_action (S:1699-1723): action_mask[o, x, y] == 1; anything out of range is invalid
@@ -50,13 +56,17 @@ static __device__ __forceinline__ void transition(const DevParams &p, Lds &l, in
     if (valid) valid = (l.vm[(o & 1) * plane + x * WW + (y >> 6)] >> (y & 63)) & 1ull;
     if (mode == MODE_REWARD && !valid) return;  // the worst-case reward of an invalid action is the environment's own team's
     const bool obs = mode != MODE_REWARD;  // a reward helper writes no observation byte
+    // Delegated and valid: the last component is being placed, the helpers route the reward from their own replay of it.
+    // With the reset to follow in this launch nothing of the placement is left to do here -- every observation byte and
+    // the whole state are about to be rewritten.
+    const bool helpers_route = mode == MODE_DELEGATED && valid;
 
     // (a delegated transition is terminal for certain: its info is written with the reward, by the last helper or below)
     if (lane == 0 && p.buf.info && mode == MODE_ALL) { p.buf.info[2 * (size_t)row] = nan(""); p.buf.info[2 * (size_t)row + 1] = nan(""); }
     if (NT > WAVE) lds_sync();  // every wavefront has read the cursor before wavefront 0 advances it (one wavefront: program order)
 
     bool done = true;  // an invalid action is a terminal transition with state and observations unchanged (quirk Q8 iii)
-    if (valid) {
+    if (valid && !(helpers_route && auto_reset)) {
         int ph, pw;
         CompRec cr = CompRec();
         if (KIND == PCBENV_SQUARE) ph = pw = p.component_n;
@@ -124,7 +134,7 @@ static __device__ __forceinline__ void transition(const DevParams &p, Lds &l, in
             STAMP(4);
             done = KIND == PCBENV_SQUARE ? !any : (l.hdr->cur < 0 || !any);  // S:1856-1869
         }  // (a reward helper: the last component has just been placed -- that is what being listed is conditional on)
-    } else if (TRAJ && full && !auto_reset && obs) {  // a fresh slot: the unchanged observation has to be written out all the same
+    } else if (!valid && TRAJ && full && !auto_reset && obs) {  // a fresh slot: the unchanged observation has to be written out all the same
         if (KIND == PCBENV_SPATIAL) build_pin_tables(p, l, lane);
         emit_features_full<KIND>(p, l, row, lane);
         if (KIND == PCBENV_SPATIAL) { emit_component_grid(p, l, row, lane); lds_sync(); }
@@ -137,7 +147,7 @@ static __device__ __forceinline__ void transition(const DevParams &p, Lds &l, in
         else if (!done) { if (lane == 0) p.buf.reward[row] = 0.0; }
     }
     // routed if everything is placed (the reward helpers' work when delegated), else the worst case (S:853-863)
-    if ((KIND == PCBENV_PIN || KIND == PCBENV_SPATIAL) && done && !(mode == MODE_DELEGATED && l.hdr->cur < 0))
+    if ((KIND == PCBENV_PIN || KIND == PCBENV_SPATIAL) && done && !helpers_route)
         terminal_reward<KIND, ROUTES>(p, l, row, lane, part, mode == MODE_REWARD ? REWARD_PARTS : 1, pos);
     STAMP(9);
     if (done && auto_reset && mode != MODE_REWARD) {
@@ -147,7 +157,7 @@ static __device__ __forceinline__ void transition(const DevParams &p, Lds &l, in
         // lds_sync() orders LDS only, so drain the stores (s_waitcnt vmcnt(0)) and meet before overwriting them.
         // Terminal wavefronts are latency-bound on the reward; the drain is free by the time they get here.
         store_drain_sync();
-        reset_env<KIND, WW, TRAJ>(p, l, e, row, lane);
+        reset_env<KIND, WW, TRAJ>(p, l, e, row, lane, mode == MODE_DELEGATED ? RESET_STATE_MASKS : RESET_ALL);
     }
     STAMP(10);
 }
@@ -168,10 +178,11 @@ static __device__ __forceinline__ void transition(const DevParams &p, Lds &l, in
 // episode walks ~67 k cycles (routing reward 33 k, reset 20 k) against 27 k for a plain transition.  Those
 // environments are known a launch ahead: once the last component is the current one, the next transition ends the
 // episode whatever the action is.  Such an environment puts itself on the list of the next launch (below), and that
-// launch starts REWARD_PARTS extra one-wavefront HELPER teams per list entry behind the environments' own workgroups
-// (k_step), each of which counts a third of the routing reward's segment pairs from its own copy of the state
-// (ROLE_REWARD) while the environment's own team (ROLE_ENV) goes straight on to the reset, so that no wavefront of the
-// launch has much more to do than a plain transition.  The environment's own team sees that it is listed from the same
+// launch starts extra one-wavefront HELPER teams per list entry (k_step): REWARD_PARTS that each count a share of the
+// routing reward's segment pairs from their own copy of the state (ROLE_REWARD) and, with PCBENV_FLAG_AUTO_RESET, one
+// that writes the feature half of the reset's observations (ROLE_FEATURES), while the environment's own team (ROLE_ENV)
+// goes straight on to its half of the reset, so that no wavefront of the launch has much more to do than a plain
+// transition.  The environment's own team sees that it is listed from the same
 // word the helpers check -- term_mark[seq & 1][e] = (launch number, list position), written together with the list
 // entry by the previous launch and by nothing during this one -- and that the last component is still the current one
 // from the same state block: state blocks are double-buffered -- a launch reads p.state and writes p.state_out, the host
@@ -181,10 +192,12 @@ static __device__ __forceinline__ void transition(const DevParams &p, Lds &l, in
 // depends on.
 #define ROLE_ENV 0
 #define ROLE_REWARD 1
+#define ROLE_FEATURES 2
 template <int KIND, int WW, bool ROUTES, bool TRAJ>
 static __device__ __forceinline__ void run_env(const DevParams &p_launch, unsigned char *smem, int e, int lane0, int *actions, int fmt, int sampled,
                                                u64 seed, u64 first_env, u64 step_index, int num_steps, int role, int part, unsigned pos) {
-    STAMP_ROWS_BY_ENV(p_launch, e);  // `p`: the launch's parameters (diagnostic build: with the stamp rows indexed by environment)
+    // `p`: the launch's parameters (diagnostic build: with the stamp rows indexed by environment, the helpers' rows behind)
+    STAMP_ROWS_BY_ENV(p_launch, role == ROLE_ENV ? e : p_launch.B + (int)pos * (REWARD_PARTS + 1) + part);
     const int H = p.H, W = p.W, HW = H * W;
     STAMP_RT(30);
     STAMP(0);
@@ -195,10 +208,11 @@ static __device__ __forceinline__ void run_env(const DevParams &p_launch, unsign
     STAMP(1);
     int mode = MODE_ALL;
     if (KIND != PCBENV_SQUARE && p.term_wgs > 0) {  // team-uniform: every lane of every team of e reads the same words
-        const bool listed = (unsigned)(mk >> 32) == p.seq && (unsigned)mk < (unsigned)p.term_cap && (role == ROLE_ENV || (unsigned)mk == pos);
+        // (listed AND this launch has started the entry's helpers: the helper grid follows the list lengths the host has seen)
+        const bool listed = (unsigned)(mk >> 32) == p.seq && (unsigned)mk < (unsigned)p.term_wgs && (role == ROLE_ENV || (unsigned)mk == pos);
         const int cur = l.hdr->cur;
         const bool last = cur >= 0 && cur == l.hdr->ncomp - 1;
-        if (listed && last) mode = role == ROLE_ENV ? MODE_DELEGATED : MODE_REWARD;
+        if (listed && last) mode = role == ROLE_ENV ? MODE_DELEGATED : role == ROLE_REWARD ? MODE_REWARD : MODE_FEATURES;
         else if (role != ROLE_ENV) return;  // a stale list entry: the environment's own team does everything
     }
     const int genv = (int)first_env + e;
@@ -212,7 +226,9 @@ static __device__ __forceinline__ void run_env(const DevParams &p_launch, unsign
         asm volatile("" : "+v"(lane));
         int o = 0, x = 0, y = 0;
         int *act = actions + per_step * (size_t)t;
-        if (sampled) {
+        if (mode == MODE_FEATURES) {
+            // (the action plays no part in a reset)
+        } else if (sampled) {
             // the tag is read whole before it is tested: `&&` would chain four dependent LDS round trips at the head of every launch
             const unsigned pa = l.hdr->pre_action, pg = l.hdr->pre_genv;
             const u64 ps = l.hdr->pre_seed, pst = l.hdr->pre_step;
@@ -251,7 +267,7 @@ static __device__ __forceinline__ void run_env(const DevParams &p_launch, unsign
             if (++slot == p.num_slots) slot = 0;
         }
     }
-    if (mode == MODE_REWARD) return;  // what is left belongs to the environment's own team
+    if (mode == MODE_REWARD || mode == MODE_FEATURES) { STAMP(11); STAMP_RT(31); return; }  // what is left belongs to the environment's own team
     presample_next(p, l, sampled && num_steps == 1, genv, seed, step_index + 1, lane0);
     // Terminal list of the NEXT launch (see above).
     if (KIND != PCBENV_SQUARE && p.term_cap > 0 && lane0 == 0) {
@@ -264,7 +280,7 @@ static __device__ __forceinline__ void run_env(const DevParams &p_launch, unsign
             const unsigned shard = ((unsigned)e * 0x9E3779B1u) >> (32 - TERM_SHARD_BITS);
             const unsigned idx = atomicAdd(p.term_cnt + (ring * TERM_SHARDS + shard) * TERM_CNT_STRIDE, 1u);
             if (idx < cps) {
-                const unsigned mpos = shard * cps + idx;
+                const unsigned mpos = idx * TERM_SHARDS + shard;  // entries in the order their helpers are launched: the first of every shard first
                 p.term_list[ring * (unsigned)p.term_cap + mpos] = e;
                 mark = ((u64)(p.seq + 1u) << 32) | mpos;
             }

@@ -54,6 +54,7 @@ struct pcbenv {
     // terminal list (Team<>::run_env): launch counter, list entries that get helper teams per launch (0 = none)
     unsigned seq;
     int term_wgs;
+    unsigned *term_seen_host;     // mapped host memory the step kernel reports its list length to (DevParams::term_seen)
     unsigned char *state_buf[2];  // double-buffered state blocks: dp.state is the current one, a step launch writes the other
     int state_cur;
     char err[256];
@@ -216,15 +217,25 @@ extern "C" int pcbenv_create(const pcbenv_config *cfg, int device, pcbenv **out)
     d.stateStride = align16((long long)d.offRank + (c.kind == PCBENV_SPATIAL ? d.P : 0));
     d.num_slots = 1; d.slot = 0;
     d.instStride = align16(pcbenv_instance_stride(&c));
-    // LDS scratch behind the state mirror
+    // LDS scratch behind the state mirror: the folded rows of window_mask where it stages them in LDS (not the one-row-
+    // per-lane cross-lane fold of one-wavefront teams up to 64 rows), doubling as the pin env's row-membership bit map
     d.ldsHf = (int)d.stateStride;
+    {
+#ifdef PCBENV_FOLD_LDS
+        const bool fold_in_lds = true;
+#else
+        const bool fold_in_lds = !(d.WW == 1 && env->threads == 64 && d.H <= 64);
+#endif
+        const int fold_words = fold_in_lds ? d.H * d.WW : 0, member_words = c.kind == PCBENV_PIN ? (d.C * d.mp + 63) / 64 : 0;
+        d.ldsHfWords = fold_words > member_words ? fold_words : member_words;
+    }
     // the class map (pin_grid emission) and the route segments (terminal reward) are never live together
-    d.ldsCls = align16(d.ldsHf + d.H * d.WW * 8);
+    d.ldsCls = align16(d.ldsHf + d.ldsHfWords * 8);
     d.ldsSeg = d.ldsCls;
     {
         const int beam = (is_pin_kind(c.kind) && c.reward_type != PCBENV_REWARD_CENTROID) ? BEAM_LDS_BYTES(c.max_num_nets, c.reward_beam_width) : 0;
         // class map of emit_pin_grid; at a reset the same zone holds the pin-id and net-mask tables (2 + 4 bytes per component cell)
-        int cls = c.kind == PCBENV_SPATIAL ? (d.H * d.W > d.C * d.mp * 6 + 4 ? d.H * d.W : d.C * d.mp * 6 + 4) : 0, seg = is_pin_kind(c.kind) ? SEG_LDS_BYTES(d.P, env->threads / 64, beam) : 0;
+        int cls = c.kind == PCBENV_SPATIAL ? (d.H * d.W > d.C * d.mp * 6 + 4 ? d.H * d.W : d.C * d.mp * 6 + 4) : 0, seg = is_pin_kind(c.kind) ? SEG_LDS_BYTES(d.P, d.N, env->threads / 64, beam) : 0;
         d.ldsBytes = align16(d.ldsCls + (cls > seg ? cls : seg));
     }
 #ifdef PCBENV_EXPERIMENTS
@@ -240,7 +251,7 @@ extern "C" int pcbenv_create(const pcbenv_config *cfg, int device, pcbenv **out)
         env->term_wgs = wgs < (int)TERM_SHARDS ? (int)TERM_SHARDS : wgs > PCBENV_TERM_CAP_MAX ? PCBENV_TERM_CAP_MAX : wgs;
     }
     d.term_cap = env->term_wgs;  // one list entry per set of helper teams
-    d.term_hpe = REWARD_PARTS;  // reward helpers per entry (pcb_step.h REWARD_PARTS)
+    d.term_hpe = REWARD_PARTS + ((c.flags & PCBENV_FLAG_AUTO_RESET) ? 1 : 0);
     DeviceGuard guard_(device);
     if (!guard_.ok) { int r = fail(0, PCBENV_EHIP, "hipSetDevice failed (no such device?)"); delete env; return r; }
     size_t sbytes = (size_t)d.stateStride * d.B, qbytes = (size_t)d.instStride * d.B * d.Q;
@@ -248,13 +259,15 @@ extern "C" int pcbenv_create(const pcbenv_config *cfg, int device, pcbenv **out)
         hipMalloc((void **)&d.queue, qbytes ? qbytes : 16) != hipSuccess ||
         hipMalloc((void **)&d.cursor_pub, 4 * (size_t)d.B) != hipSuccess ||
         hipMalloc((void **)&d.term_list, 4 * (size_t)4 * PCBENV_TERM_CAP_MAX) != hipSuccess || hipMalloc((void **)&d.term_cnt, 4 * TERM_SHARDS * TERM_CNT_STRIDE * 4) != hipSuccess || hipMalloc((void **)&d.term_arrive, 8 * (size_t)PCBENV_TERM_CAP_MAX) != hipSuccess ||
-        hipMalloc((void **)&d.term_mark, 16 * (size_t)d.B) != hipSuccess) {
+        hipMalloc((void **)&d.term_mark, 16 * (size_t)d.B) != hipSuccess ||
+        hipHostMalloc((void **)&env->term_seen_host, 64, hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void **)&d.term_seen, env->term_seen_host, 0) != hipSuccess) {
         int r = fail(0, PCBENV_EHIP, "hipMalloc failed");
         pcbenv_destroy(env);
         return r;
     }
 #ifdef PCBENV_STAMPS
-    { const char *ev = getenv("PCBENV_STAMPS"); if (ev && ev[0] == '1') { hipMalloc((void **)&d.dbg, (size_t)d.B * 32 * 8); hipMemset(d.dbg, 0, (size_t)d.B * 32 * 8); } }
+    { const char *ev = getenv("PCBENV_STAMPS"); if (ev && ev[0] == '1') { hipMalloc((void **)&d.dbg, (size_t)(d.B + PCBENV_TERM_CAP_MAX * (REWARD_PARTS + 1)) * 32 * 8); hipMemset(d.dbg, 0, (size_t)(d.B + PCBENV_TERM_CAP_MAX * (REWARD_PARTS + 1)) * 32 * 8); } }
 #endif
     hipMemset(env->state_buf[0], 0, sbytes);
     hipMemset(env->state_buf[1], 0, sbytes);
@@ -265,6 +278,7 @@ extern "C" int pcbenv_create(const pcbenv_config *cfg, int device, pcbenv **out)
     hipMemset(d.term_cnt, 0, 4 * TERM_SHARDS * TERM_CNT_STRIDE * 4);
     hipMemset(d.term_arrive, 0, 8 * (size_t)PCBENV_TERM_CAP_MAX);
     hipMemset(d.term_mark, 0, 16 * (size_t)d.B);
+    *env->term_seen_host = 0u;
     hipDeviceSynchronize();
     *out = env;
     return PCBENV_OK;
@@ -288,6 +302,7 @@ extern "C" void pcbenv_destroy(pcbenv *env) {
     if (env->dp.term_cnt) hipFree(env->dp.term_cnt);
     if (env->dp.term_mark) hipFree(env->dp.term_mark);
     if (env->dp.term_arrive) hipFree(env->dp.term_arrive);
+    if (env->term_seen_host) hipHostFree(env->term_seen_host);
     if (env->scratch) hipFree(env->scratch);
     delete env;
 }
@@ -442,7 +457,13 @@ static int dispatch_step(pcbenv *env, int *actions, int fmt, int sampled, u64 se
     // no buffer swap -- it runs without helpers, keeps no list and works on the state blocks in place.
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     const bool capturing = hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
-    d.term_wgs = (num_steps == 1 && !capturing) ? env->term_wgs : 0;  // reward helpers: one transition per launch only
+    d.term_wgs = 0;
+    if (num_steps == 1 && !capturing && env->term_wgs > 0) {  // reward helpers: one transition per launch only
+        // as many entries' helpers as the lists have lately been long (+ 25 %, + 2 per shard; never none: a shard's first entry)
+        const unsigned seen = *(volatile unsigned *)env->term_seen_host;
+        const long long want = (long long)TERM_SHARDS * ((long long)seen + seen / 4 + 2);
+        d.term_wgs = (int)(want < env->term_wgs ? want : env->term_wgs);
+    }
     if (capturing) d.term_cap = 0;
     // double-buffered state blocks: read the current ones, write the others
     d.state = env->state_buf[env->state_cur];
@@ -734,7 +755,10 @@ extern "C" int pcbenv_queue_cursors(pcbenv *env, uint32_t *min_out, uint32_t *ma
 extern "C" int pcbenv_debug_stamps(pcbenv *env, unsigned long long *host) {  // diagnostic build only
     if (!env || !env->dp.dbg) return -1;
     hipDeviceSynchronize();
-    return hipMemcpy(host, env->dp.dbg, (size_t)env->dp.B * 32 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
+    const size_t rows = (size_t)env->dp.B + (size_t)env->dp.term_cap * (REWARD_PARTS + 1);  // environments, then the helpers
+    const int rc = hipMemcpy(host, env->dp.dbg, rows * 32 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
+    hipMemset(env->dp.dbg, 0, rows * 32 * 8);
+    return rc;
 }
 #endif
 

@@ -77,7 +77,20 @@ for stagger in (False, True):
         if k < 2 or kind in seen:
             continue
         seen.add(kind)
-        buf = np.zeros((B, 32), np.uint64)
+        cap = 4096 * 3
+        buf = np.zeros((B + cap, 32), np.uint64)
         assert env._L.pcbenv_debug_stamps(env._h, buf.ctypes.data) == 0
-        report(f"{name} x{B} {kind}", buf.astype(np.int64), done)
+        allrows = buf.astype(np.int64)
+        report(f"{name} x{B} {kind}", allrows[:B], done)
+        hs = allrows[B:]
+        hs = hs[hs[:, 30] > 0]
+        if len(hs):  # reward helpers of this launch: when they started / ended relative to the first wavefront of the launch
+            t0 = allrows[:B, 30].min()
+            q = lambda v, f: float(np.quantile(v - t0, f)) * 10e-3
+            print(f"  reward helpers: {len(hs)} ran; starts p1/p50/p99/max {q(hs[:, 30], .01):.2f}/{q(hs[:, 30], .5):.2f}/{q(hs[:, 30], .99):.2f}/{q(hs[:, 30], 1):.2f} us, "
+                  f"ends p50/p99/max {q(hs[:, 31], .5):.2f}/{q(hs[:, 31], .99):.2f}/{q(hs[:, 31], 1):.2f} us, median cycles {int(np.median(hs[:, 11] - hs[:, 0]))}")
+            for n_, x, y in TERM[:13]:
+                ok = (hs[:, x] > 0) & (hs[:, y] > 0)
+                if ok.any():
+                    print(f"    helper {n_:28s} {int(np.median(hs[ok, y] - hs[ok, x])):7d}")
     env.close()

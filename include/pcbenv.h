@@ -157,9 +157,11 @@ int pcbenv_bind_buffers(pcbenv *env, const pcbenv_buffers *buffers);
 enum pcbenv_option {
     PCBENV_OPT_STREAM_THRESHOLD_BYTES = 1, /* cell-tensor bytes per launch above which observation stores bypass the
                                               caches (`nt`); default 256 MiB = the Infinity Cache; 0 = always */
-    PCBENV_OPT_TERMINAL_TEAMS = 2,         /* workgroups of four-wavefront teams a one-transition launch reserves for the
-                                              environments that are certain to end their episode in it (k_step_mixed);
-                                              default num_envs / 8 for one-wavefront configurations, 0 = plain kernel */
+    PCBENV_OPT_TERMINAL_TEAMS = 2,         /* capacity of the terminal list: environments whose next transition is certain to
+                                              end their episode get helper wavefronts in that launch (two that share the routing
+                                              reward, one that writes the feature half of the reset), so that a batch whose
+                                              episodes end at different times steps as fast as one in lock-step; default
+                                              num_envs / 8 for the pin kinds with one wavefront per environment, 0 = off */
     PCBENV_OPT_GEN_GRID = 3,               /* workgroups of a refill launch of the on-device generator (default 2 048) */
     PCBENV_OPT_GEN_LANES = 4               /* lanes per environment of the generator kernel: 0 = narrowest the
                                               configuration allows, 32 / 64 force a wider group; before enabling it */
@@ -190,7 +192,9 @@ int pcbenv_load_instances(pcbenv *env, const int32_t *env_ids, int32_t n, int32_
  * rewrites its observations.  Never called implicitly by pcbenv_step. */
 int pcbenv_reset(pcbenv *env, const uint8_t *mask_dev, void *stream);
 
-/* step(): one transition of every environment with the given actions. */
+/* step(): one transition of every environment with the given actions.
+ * (A launch issued while `stream` is being captured into a hipGraph will be replayed with the very same arguments: it
+ * then runs without the helper wavefronts of the terminal list and updates the state blocks in place -- same results.) */
 int pcbenv_step(pcbenv *env, const int32_t *actions_dev, int32_t action_format, void *stream);
 
 /* Uniform draw over the currently legal actions of every environment
@@ -260,7 +264,8 @@ int pcbenv_set_state(pcbenv *env, const void *host_src, void *stream);
 /* Bit-packed legal-action mask of the current component, library-owned device
  * memory: uint64 [B, 2, H, ceil(W/64)] (orientation 0/1; pin kinds: 2 = 0, 3 = 1;
  * square: plane 0 only), bit y of word [b, o, x, y/64] = action_mask[b, o, x, y].
- * Also the row stride between environments in bytes. */
+ * Also the row stride between environments in bytes.  The state blocks are double-buffered (a step launch reads one
+ * set and writes the other): ask again after every pcbenv_step* / pcbenv_rollout_sampled, the pointer alternates. */
 const uint64_t *pcbenv_mask_bits(const pcbenv *env, int64_t *env_stride_bytes);
 
 #ifdef __cplusplus

@@ -56,7 +56,6 @@ struct DevParams {
     int term_wgs, term_cap, term_hpe;  // term_hpe = helper teams per entry: REWARD_PARTS, + 1 feature helper with PCBENV_FLAG_AUTO_RESET
     int *term_list;
     unsigned *term_cnt;
-    u64 *term_mark;    // [2][B]: (launch number << 32 | list position) of environment e for launches of that parity
     u64 *term_arrive;  // [term_cap]: where the shares of a routing reward meet (terminal_reward)
     unsigned *term_seen;  // host memory: the longest shard of the latest launch's list (sizes later helper grids)
     unsigned char *state_out;  // the state blocks this launch writes (p.state: the ones it reads); equal for in-place kernels
@@ -105,7 +104,9 @@ struct __attribute__((aligned(16))) EnvHdr {
     u64 pre_seed, pre_step;
     unsigned pre_action;             // o | x << 8 | y << 16 | 1 << 31
     unsigned pre_genv;
-    unsigned rsv[2];
+    // Terminal list (run_env): the launch number for which this environment sits on the list of environments that are
+    // certain to end their episode, and its entry there; anything else = not listed.
+    unsigned term_seq, term_pos;
 };
 static_assert(sizeof(EnvHdr) == HDR_BYTES, "header size");
 

@@ -15,7 +15,7 @@ __global__ __launch_bounds__(64 * NW) void k_reset(DevParams p, const unsigned c
     T::template reset_env<KIND, WW, true>(p, l, e, row, lane);
     if (lane == 0) {
         l.hdr->pre_action = 0u;  // the mask changed under any presampled action
-        if (p.term_cap > 0) p.term_mark[(size_t)((p.seq + 1u) & 1u) * p.B + e] = 0ull;  // and the environment leaves the terminal list of the next step launch (its helpers find a stale entry)
+        l.hdr->term_seq = 0u;    // and the environment leaves the terminal list of the next step launch (its helpers find a stale entry)
         p.buf.reward[row] = 0.0;
         p.buf.done[row] = 0;
         if (p.buf.info) { p.buf.info[2 * (size_t)row] = nan(""); p.buf.info[2 * (size_t)row + 1] = nan(""); }
@@ -57,13 +57,26 @@ __global__ __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(64 * NW)
         // (wave-uniform values the compiler cannot see as such: kept in scalar registers, like blockIdx.x)
         e = __builtin_amdgcn_readfirstlane(p.term_list[ring * (unsigned)p.term_cap + pos]);
         role = part < REWARD_PARTS ? ROLE_REWARD : ROLE_FEATURES;
+#ifndef PCBENV_X_NO_BOOKKEEPING
     } else if (p.term_cap > 0 && e == 0 && threadIdx.x < TERM_SHARDS) {
         // list bookkeeping, by the first environment workgroup: the ring after next starts empty, and the host learns how
         // long this launch's shards are (any later launch may read it, whenever: it only sizes helper grids)
         store_agent(p.term_cnt + ((((p.seq + 2u) & 3u) * TERM_SHARDS + threadIdx.x) * TERM_CNT_STRIDE), 0u);
         unsigned longest = load_agent(p.term_cnt + (((p.seq & 3u) * TERM_SHARDS + threadIdx.x) * TERM_CNT_STRIDE));
         for (int o = TERM_SHARDS / 2; o > 0; o >>= 1) longest = max(longest, (unsigned)__shfl_xor((int)longest, o, TERM_SHARDS));
-        if (threadIdx.x == 0) __hip_atomic_store(p.term_seen, longest, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // ... the SHORTEST of the last four launches' longest shards: with episodes in lock-step the list is full once per
+        // episode and empty otherwise -- sized on that one launch, the launches that follow would each start ~2 000 idle
+        // helper workgroups (+ 4 % on the lock-step loop) -- while staggered phases give steady lengths, which the minimum
+        // tracks as well.  (Kept per launch on the device: the host reads whenever it enqueues, many times per launch or
+        // once in many.)
+        if (threadIdx.x == 0) {
+            unsigned *hist = p.term_cnt + 4u * TERM_SHARDS * TERM_CNT_STRIDE;  // four words behind the counters
+            hist[p.seq & 3u] = longest;
+            unsigned least = longest;
+            for (unsigned i = 1; i < 4; i++) least = min(least, hist[(p.seq + i) & 3u]);
+            __hip_atomic_store(p.term_seen, least, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+#endif
     }
     Team<64 * NW>::template run_env<KIND, WW, ROUTES, TRAJ>(p, smem, e, threadIdx.x, actions, fmt, sampled, seed, first_env, step_index,
                                                            num_steps, role, part, pos);

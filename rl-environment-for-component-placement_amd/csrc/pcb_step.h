@@ -201,13 +201,12 @@ static __device__ __forceinline__ void run_env(const DevParams &p_launch, unsign
     const int H = p.H, W = p.W, HW = H * W;
     STAMP_RT(30);
     STAMP(0);
-    // (requested ahead of the state block, so that its round trip is the state block's)
-    const u64 mk = p.term_wgs > 0 ? p.term_mark[(size_t)(p.seq & 1u) * p.B + e] : 0ull;
     load_state(smem, p, e, lane0);
     Lds l = carve(smem, p);
     STAMP(1);
     int mode = MODE_ALL;
     if (KIND != PCBENV_SQUARE && p.term_wgs > 0) {  // team-uniform: every lane of every team of e reads the same words
+        const u64 mk = ((u64)l.hdr->term_seq << 32) | l.hdr->term_pos;
         // (listed AND this launch has started the entry's helpers: the helper grid follows the list lengths the host has seen)
         const bool listed = (unsigned)(mk >> 32) == p.seq && (unsigned)mk < (unsigned)p.term_wgs && (role == ROLE_ENV || (unsigned)mk == pos);
         const int cur = l.hdr->cur;
@@ -285,7 +284,7 @@ static __device__ __forceinline__ void run_env(const DevParams &p_launch, unsign
                 mark = ((u64)(p.seq + 1u) << 32) | mpos;
             }
         }
-        p.term_mark[(size_t)((p.seq + 1u) & 1u) * p.B + e] = mark;
+        l.hdr->term_seq = (unsigned)(mark >> 32); l.hdr->term_pos = (unsigned)mark;
     }
     STAMP(20);
     store_state(smem, p, e, lane0);

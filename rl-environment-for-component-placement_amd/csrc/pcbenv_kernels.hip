@@ -258,8 +258,7 @@ extern "C" int pcbenv_create(const pcbenv_config *cfg, int device, pcbenv **out)
     if (hipMalloc((void **)&env->state_buf[0], sbytes) != hipSuccess || hipMalloc((void **)&env->state_buf[1], sbytes) != hipSuccess ||
         hipMalloc((void **)&d.queue, qbytes ? qbytes : 16) != hipSuccess ||
         hipMalloc((void **)&d.cursor_pub, 4 * (size_t)d.B) != hipSuccess ||
-        hipMalloc((void **)&d.term_list, 4 * (size_t)4 * PCBENV_TERM_CAP_MAX) != hipSuccess || hipMalloc((void **)&d.term_cnt, 4 * TERM_SHARDS * TERM_CNT_STRIDE * 4) != hipSuccess || hipMalloc((void **)&d.term_arrive, 8 * (size_t)PCBENV_TERM_CAP_MAX) != hipSuccess ||
-        hipMalloc((void **)&d.term_mark, 16 * (size_t)d.B) != hipSuccess ||
+        hipMalloc((void **)&d.term_list, 4 * (size_t)4 * PCBENV_TERM_CAP_MAX) != hipSuccess || hipMalloc((void **)&d.term_cnt, 4 * TERM_SHARDS * TERM_CNT_STRIDE * 4 + 16) != hipSuccess || hipMalloc((void **)&d.term_arrive, 8 * (size_t)PCBENV_TERM_CAP_MAX) != hipSuccess ||
         hipHostMalloc((void **)&env->term_seen_host, 64, hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void **)&d.term_seen, env->term_seen_host, 0) != hipSuccess) {
         int r = fail(0, PCBENV_EHIP, "hipMalloc failed");
@@ -275,9 +274,8 @@ extern "C" int pcbenv_create(const pcbenv_config *cfg, int device, pcbenv **out)
     d.state = d.state_out = env->state_buf[0];
     hipMemset(d.queue, 0, qbytes ? qbytes : 16);
     hipMemset(d.cursor_pub, 0, 4 * (size_t)d.B);
-    hipMemset(d.term_cnt, 0, 4 * TERM_SHARDS * TERM_CNT_STRIDE * 4);
+    hipMemset(d.term_cnt, 0, 4 * TERM_SHARDS * TERM_CNT_STRIDE * 4 + 16);
     hipMemset(d.term_arrive, 0, 8 * (size_t)PCBENV_TERM_CAP_MAX);
-    hipMemset(d.term_mark, 0, 16 * (size_t)d.B);
     *env->term_seen_host = 0u;
     hipDeviceSynchronize();
     *out = env;
@@ -300,7 +298,6 @@ extern "C" void pcbenv_destroy(pcbenv *env) {
     if (env->dp.cursor_pub) hipFree(env->dp.cursor_pub);
     if (env->dp.term_list) hipFree(env->dp.term_list);
     if (env->dp.term_cnt) hipFree(env->dp.term_cnt);
-    if (env->dp.term_mark) hipFree(env->dp.term_mark);
     if (env->dp.term_arrive) hipFree(env->dp.term_arrive);
     if (env->term_seen_host) hipHostFree(env->term_seen_host);
     if (env->scratch) hipFree(env->scratch);
@@ -459,10 +456,14 @@ static int dispatch_step(pcbenv *env, int *actions, int fmt, int sampled, u64 se
     const bool capturing = hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
     d.term_wgs = 0;
     if (num_steps == 1 && !capturing && env->term_wgs > 0) {  // reward helpers: one transition per launch only
-        // as many entries' helpers as the lists have lately been long (+ 25 %, + 2 per shard; never none: a shard's first entry)
+        // as many entries' helpers as the lists have lately been long (k_step reports it: + 25 %, + 2 per shard; never none:
+        // a shard's first entry)
         const unsigned seen = *(volatile unsigned *)env->term_seen_host;
         const long long want = (long long)TERM_SHARDS * ((long long)seen + seen / 4 + 2);
         d.term_wgs = (int)(want < env->term_wgs ? want : env->term_wgs);
+#ifdef PCBENV_X_NO_HELPERS
+        d.term_wgs = 0;
+#endif
     }
     if (capturing) d.term_cap = 0;
     // double-buffered state blocks: read the current ones, write the others
@@ -703,10 +704,15 @@ extern "C" int pcbenv_set_state(pcbenv *env, const void *host_src, void *stream)
     if (env->gen_on) return fail(env, PCBENV_ESTATE, "restoring a checkpoint is not supported while the on-device generator runs (its streams are not part of the state)");
     DEVICE_GUARD(env);
     const size_t sb = (size_t)env->dp.stateStride * env->dp.B;
-    HIP_TRY(env, hipMemcpyAsync(env->dp.state, host_src, sb, hipMemcpyHostToDevice, (hipStream_t)stream));
+    // The terminal-list marks in a checkpoint refer to lists of the run that wrote it: restored environments are not listed.
+    std::vector<unsigned char> blob((const unsigned char *)host_src, (const unsigned char *)host_src + sb);
     std::vector<unsigned> cur((size_t)env->dp.B);  // the published copy of the queue cursors follows the restored headers
-    for (int i = 0; i < env->dp.B; i++)
-        cur[(size_t)i] = ((const EnvHdr *)((const unsigned char *)host_src + (size_t)i * env->dp.stateStride))->qcursor;
+    for (int i = 0; i < env->dp.B; i++) {
+        EnvHdr *hd = (EnvHdr *)(blob.data() + (size_t)i * env->dp.stateStride);
+        hd->term_seq = 0u;
+        cur[(size_t)i] = hd->qcursor;
+    }
+    HIP_TRY(env, hipMemcpyAsync(env->dp.state, blob.data(), sb, hipMemcpyHostToDevice, (hipStream_t)stream));
     HIP_TRY(env, hipMemcpyAsync(env->dp.cursor_pub, cur.data(), 4 * (size_t)env->dp.B, hipMemcpyHostToDevice, (hipStream_t)stream));
     HIP_TRY(env, hipStreamSynchronize((hipStream_t)stream));
     return PCBENV_OK;

@@ -33,6 +33,25 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 
+# the UNMODIFIED reference Python env timed in the survey container (Icelake-class Xeon VM, 1 thread,
+# Python 3.10.12, numpy 2.2.6, scipy 1.15.3; step() wall time under uniform-random legal actions).  The reference cannot
+# travel to the GPU box, so these are quoted, labelled, next to the port's numbers measured in this run.
+def _ref(step_ms, reset_ms, per_core, entry):
+    return {"label": "reference Python, survey container, 1 core (BASELINE.md section 2; not measured in this run)", "step_ms": step_ms,
+            "reset_ms": reset_ms, "env_steps_per_sec_per_core": per_core, "entry_point": entry}
+
+
+REFERENCE_PYTHON = {
+    ("c1", "centroid"): _ref(0.011, 0.013, 88000, "environment/dummy_env_square.py:115"),
+    ("c2", "centroid"): _ref(0.128, 0.197, 7800, "environment/dummy_env_rectangular.py:353"),
+    ("c3", "centroid"): _ref(0.72, 1.04, 1380, "environment/dummy_env_rectangular_pin.py:1599"),
+    ("c3", "both"): _ref(0.90, 1.01, 1110, "environment/dummy_env_rectangular_pin.py:1599"),
+    ("c4", "centroid"): _ref(0.89, 1.14, 1120, "environment/dummy_env_rectangular_pin_spatial.py:1551"),
+    ("c5", "centroid"): _ref(3.73, 4.97, 270, "environment/dummy_env_rectangular_pin_spatial.py:1551"),
+    ("c5", "both"): _ref(4.16, 4.99, 240, "environment/dummy_env_rectangular_pin_spatial.py:1551"),
+}
+
+
 def algorithmic_bytes_per_env_step(cfg) -> int:
     """1 byte per cell for grid / action_mask / pin_grid, 8-byte table records."""
     from pcbenv.config import KIND_SPATIAL
@@ -68,30 +87,78 @@ def rollout_leg(cfg, args, B, dev_index, rank, T):
         env.generate_instances()
     env.reset()
     acts = torch.empty((T, B, 3), dtype=torch.int32, device=env.device)
-    launches = max(1, args.steps // T)
+    launches = max(8, args.steps // T)  # at least eight launches whatever --steps is: a spread, not a single sample
     pos = 1
     for _ in range(2):  # warm-up launches
         env.select_slot(pos); env.rollout_steps(0, T, out=acts); pos = (pos + T) % S
-    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(launches + 1)]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ev[0].record()
+    evs[0].record()
     for k in range(launches):
         env.select_slot(pos); env.rollout_steps((2 + k) * T, T, out=acts); pos = (pos + T) % S
-    ev[1].record()
+        evs[k + 1].record()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    kernel_ms = ev[0].elapsed_time(ev[1]) / launches
+    per_launch = [evs[k].elapsed_time(evs[k + 1]) for k in range(launches)]
+    kernel_ms = evs[0].elapsed_time(evs[launches]) / launches
     nbytes = trajectory_bytes_per_env_step(cfg)
     gen_errors = env.device_instance_errors() if args.instances == "device" else None
     env.close()
     gbps = nbytes * B * T / (kernel_ms * 1e-3) / 1e9
     return {"value": round(B * T * launches / dt, 1), "unit": "env-steps/s", "steps_per_launch": T, "num_slots": S,
             "launches": launches, "ms_per_step": round(dt / (launches * T) * 1e3, 5), "kernel_ms_per_launch": round(kernel_ms, 4),
+            "kernel_ms_per_launch_min_median_max": [round(min(per_launch), 4), round(float(np.median(per_launch)), 4), round(max(per_launch), 4)],
             "bytes_written_per_env_step": nbytes, "achieved_GBps": round(gbps, 1), "frac_of_8TBps": round(gbps / 8000.0, 4),
             "algorithmic_GBps": round(algorithmic_bytes_per_env_step(cfg) * B * T / (kernel_ms * 1e-3) / 1e9, 1),
             "instances": args.instances, "generator_errors": gen_errors,
             "note": "every tensor of every step kept (trajectory layout), float64 feature tensors included; this rank only"}
+
+
+def external_actions_staggered_leg(cfg, args, B, dev_index, rank):
+    """The loop a policy runs (reference: utils/agent/utils.py:221-256, agent/random/random_policy_square.py:38-56): the
+    action tensor comes from ANOTHER kernel between the steps (here the stand-alone uniform sampler, as a policy's
+    forward would produce it), one pcbenv_step launch per step, and the episodes end at different times -- the phases
+    are spread evenly, 1 / max_num_components of the batch ends an episode in every launch.  The terminal list and
+    its helper wavefronts are what keeps such a launch as short as a lock-step one."""
+    from pcbenv.batched_env import BatchedPlacementEnv
+    from pcbenv.config import KIND_SQUARE
+    L = max(1, cfg.max_num_components if cfg.kind != KIND_SQUARE else 4)
+    steps = max(args.steps, 8 * L)
+    env = BatchedPlacementEnv(cfg, B, device=f"cuda:{dev_index}", queue_depth=max(args.queue_depth, 2), run_seed=args.run_seed,
+                              first_env_index=rank * B, auto_reset=True, threads_per_env=args.threads_per_env)
+    env.generate_instances()
+    env.reset()
+    acts = torch.empty((B, 3), dtype=torch.int32, device=env.device)
+    idx = torch.arange(B, device=env.device)
+    for t in range(2 * L):  # spread the phases: environment i restarts once more after step i % L
+        env.sample_actions(t, out=acts); env.step(acts)
+        if t < L:
+            env.reset((idx % L == t).to(torch.uint8))
+    for t in range(max(args.warmup, 2 * L)):
+        env.sample_actions(100 + t, out=acts); env.step(acts)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        env.sample_actions(1000 + k, out=acts)
+        env.step(acts)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    done_frac = float(env.done.float().mean())
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(64)]
+    for k, (e0, e1) in enumerate(ev):  # the step launch alone, by events on the launch stream
+        env.sample_actions(5000 + k, out=acts)
+        e0.record(); env.step(acts); e1.record()
+    torch.cuda.synchronize()
+    step_ms = float(np.median([a.elapsed_time(b) for a, b in ev]))
+    env.close()
+    b_alg = algorithmic_bytes_per_env_step(cfg)
+    return {"value": round(B * steps / dt, 1), "unit": "env-steps/s", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 5),
+            "step_kernel_ms": round(step_ms, 5), "frac_of_8TBps": round(b_alg * B / (step_ms * 1e-3) / 1e9 / 8000.0, 4),
+            "frac_of_8TBps_whole_loop": round(b_alg * B * steps / dt / 1e9 / 8000.0, 4),
+            "terminal_fraction_per_launch": round(done_frac, 4),
+            "note": "actions from a separate kernel between the steps (k_sample), one pcbenv_step launch per step, episode phases spread "
+                    "evenly; ms_per_step includes the sampler launch, step_kernel_ms is the step launch alone (median of 64, HIP events); this rank only"}
 
 
 def fresh_instances_leg(cfg, args, B, dev_index, rank):
@@ -116,6 +183,7 @@ def fresh_instances_leg(cfg, args, B, dev_index, rank):
     errors = env.device_instance_errors()
     env.close()
     return {"value": round(B * steps / dt, 1), "unit": "env-steps/s", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 5),
+            "frac_of_8TBps": round(algorithmic_bytes_per_env_step(cfg) * B * steps / dt / 1e9 / 8000.0, 4),
             "queue_depth": 64, "generator_errors": errors,
             "note": "same loop and kernel; a new instance at every reset, generated on the GPU inside the timed region; this rank only"}
 
@@ -245,6 +313,7 @@ def main():
                     help="also time the persistent rollout kernel with this many steps per launch in the trajectory layout "
                          "(reported as `rollout`; 0 = skip)")
     ap.add_argument("--no-fresh-leg", action="store_true", help="skip the extra leg with a fresh on-device instance at every reset")
+    ap.add_argument("--no-staggered-leg", action="store_true", help="skip the extra leg with external actions and staggered episode phases")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     args = ap.parse_args()
@@ -271,6 +340,9 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    if args.backend == "nccl" and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} over RCCL needs {world} visible GPUs, this node shows {torch.cuda.device_count()} "
+                         "(one rank per GPU; --backend gloo only rehearses the multi-rank path on fewer cards)")
     if args.adv_allgather is None:
         args.adv_allgather = world > 1
     dev_index = local_rank if args.device_index < 0 else args.device_index
@@ -391,6 +463,30 @@ def main():
 
     gen_errors_main = env.device_instance_errors() if args.instances == "device" and cfg.kind != 0 else None
     env.close()
+    # N > 1: BASELINE.json's config 4 (pin_spatial 64x64, 4 096 environments per GPU, sharded) next to the headline workload,
+    # which stays c3 for every N so that the per-N values of one scaling run are comparable
+    config4 = None
+    if dist and args.config == "c3" and not args.incremental:
+        cfg4 = named_config("c4", args.reward)
+        env4 = BatchedPlacementEnv(cfg4, B, device=f"cuda:{dev_index}", queue_depth=args.queue_depth, run_seed=args.run_seed,
+                                   first_env_index=rank * B, auto_reset=True, threads_per_env=args.threads_per_env)
+        env4.generate_instances(); env4.reset()
+        a4 = torch.empty((B, 3), dtype=torch.int32, device=env4.device)
+        n4 = max(64, args.steps)
+        for t in range(32):
+            env4.rollout_step(t, out=a4)
+        torch.cuda.synchronize(); dist.barrier()
+        t4 = time.perf_counter()
+        for t in range(n4):
+            env4.rollout_step(32 + t, out=a4)
+        torch.cuda.synchronize(); dist.barrier()
+        t4 = over_ranks(time.perf_counter() - t4)[0]
+        env4.close()
+        config4 = {"workload": "c4: pin_spatial 64x64, 16 components, 48 pins", "envs_per_gpu": B, "steps": n4,
+                   "value": round(world * B * n4 / t4, 1), "unit": "env-steps/s (all ranks)", "ms_per_step": round(t4 / n4 * 1e3, 5)}
+    staggered = None
+    if args.loop == "fused" and not args.incremental and cfg.kind != 0 and not args.no_staggered_leg:
+        staggered = external_actions_staggered_leg(cfg, args, B, dev_index, rank)
     fresh = None
     if args.instances == "replay" and args.loop == "fused" and not args.incremental and cfg.kind != 0 and not args.no_fresh_leg:
         fresh = fresh_instances_leg(cfg, args, B, dev_index, rank)
@@ -440,14 +536,29 @@ def main():
                    "sample": f"{sample_envs} envs x {sample_steps} steps of the same instances and action stream (oracle/pcbenv_oracle.c, OpenMP)",
                    "single_thread_value": round(res[1][0], 1), "parity_with_gpu": bool(all(v[1] for v in res.values())),
                    "parity_scope": "reward + done of every sampled env-step, all observation tensors of 32 environments after the last step",
-                   "cpu_model": host_cpu_model(), "host_logical_cpus": os.cpu_count()}
+                   "cpu_model": host_cpu_model(), "host_logical_cpus": os.cpu_count(),
+                   "threads_note": "1 and 16 threads: 16 is one GPU's share of this host (the pool's limit for a 1-GPU lease), not all physical cores",
+                   "reference_python": REFERENCE_PYTHON.get((args.config, args.reward))}
+        L = cfg.max_num_components if cfg.kind != 0 else None
+        lockstep = cfg.kind != 0 and cfg.min_num_components == cfg.max_num_components and args.loop == "fused"
+        term_in_region = sum(1 for k in range(args.warmup, args.warmup + args.steps) if k % L == L - 1) if lockstep else None
+        rccl_version = None
+        if dist and args.backend == "nccl":
+            try:
+                rccl_version = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:
+                rccl_version = "unknown"
         line = {"metric": "env_steps_per_sec", "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5),
                 "ms_per_step_repeats": {"n": len(repeats_ms), "median": round(float(np.median(repeats_ms)), 5),
                                         "min": round(min(repeats_ms), 5), "max": round(max(repeats_ms), 5)},
                 "per_rank_env_steps_per_sec": [round(B * args.steps / t, 1) for t in per_rank_s],
                 "world_size_observed": (dist.get_world_size() if dist else 1),
-                "backend": (("rccl" if args.backend == "nccl" else args.backend) if dist else None),
+                "backend": (("rccl" if args.backend == "nccl" else args.backend) if dist else None), "rccl_version": rccl_version,
+                "per_rank_first_env_index": [r * B for r in range(world)],
+                "terminal_launches_in_region": term_in_region,
+                "terminal_launches_note": (f"episodes are {L} steps and in lock-step: a region of {args.steps} steps from step {args.warmup} holds "
+                                           f"{term_in_region} terminal launches (reward + reset of every environment), {args.steps / L:.2f} on average") if lockstep else None,
                 "adv_allgather_bytes_per_rank": (16 * B * 4 if adv is not None else 0),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
                 "data": "synthetic (reference-exact instance streams, seeds 1000003*run_seed+env" + (", generated on the GPU, a new instance at every reset" if args.instances == "device" else ", queued once and replayed") + "; uniform legal actions drawn on device)",
@@ -457,8 +568,8 @@ def main():
                            "fresh_instance_every_reset": args.instances == "device", "generator_errors": gen_errors_main, "incremental_obs": bool(args.incremental), "loop": args.loop, "steps_per_host_call": chunk,
                            "instance_generation_s": round(t_gen, 2),
                            "store_policy": "sc1 nt (streaming)" if cfg.cell_tensor_bytes_per_step(args.incremental) * B
-                           > int(os.environ.get("PCBENV_STREAM_THRESHOLD_MB", "256")) * (1 << 20) else "sc1 (write-through)"},
-                "roofline": roof, "cpu_baseline": cpu, "fresh_instances": fresh, "rollout": rollout}
+                           > 256 * (1 << 20) else "sc1 (write-through)"},
+                "roofline": roof, "cpu_baseline": cpu, "north_star_config4": config4, "external_actions_staggered": staggered, "fresh_instances": fresh, "rollout": rollout}
         print(json.dumps(line), flush=True)
     if dist:
         dist.barrier()  # rank 0 has printed: leave together

@@ -255,8 +255,11 @@ int pcbenv_get_instances(pcbenv *env, int32_t slot, void *host_dst, void *stream
  * consumed by every environment and may be refilled.  Synchronises with `stream`. */
 int pcbenv_queue_cursors(pcbenv *env, uint32_t *min_out, uint32_t *max_out, void *stream);
 
-/* Checkpoint / resume of the library-owned environment state (all state blocks, pcbenv_state_bytes() bytes of
- * host memory; the instance queue is an input and is reloaded by the caller).  Synchronous w.r.t. `stream`. */
+/* Checkpoint / resume of the library-owned environment state: pcbenv_state_bytes() bytes of host memory holding all state
+ * blocks and -- once pcbenv_instgen_device_enable has been called, when the size grows accordingly -- the on-device
+ * generator's streams, counters and queued records, so that a resumed run draws the very instances the original would
+ * have (restore into a handle of the same configuration with the generator enabled as well).  A host-fed queue is an
+ * input and is reloaded by the caller.  Synchronous w.r.t. `stream`. */
 int64_t pcbenv_state_bytes(const pcbenv *env);
 int pcbenv_get_state(pcbenv *env, void *host_dst, void *stream);
 int pcbenv_set_state(pcbenv *env, const void *host_src, void *stream);

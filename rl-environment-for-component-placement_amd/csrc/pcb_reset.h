@@ -99,9 +99,11 @@ template <int KIND, int WW, bool TRAJ> static __device__ inline void reset_env(c
         if (lane == 0) {
             l.hdr->ncomp = (short)nc; l.hdr->nnets = (short)nn; l.hdr->npins = (short)np; l.hdr->cur = 0;
             l.hdr->qcursor += 1; l.hdr->episode += 1;
-            if (owner) store_agent(p.cursor_pub + e, l.hdr->qcursor);
         }
         lds_sync();
+        // The advanced cursor tells the generator that the record's slot may be overwritten: published only now that every
+        // wavefront of the team has its part of the record (the loads were waited for before the LDS writes above).
+        if (owner && lane == 0) store_agent(p.cursor_pub + e, l.hdr->qcursor);
         if (KIND == PCBENV_PIN && lane < WAVE) {
             // quirk Q1: rows [component, pin_id] collide; the last writer in self.pins order wins.  Wavefront 0 keeps
             // the (component, pin_id) keys of its lanes' slots in registers and walks the pins with v_readlane:

@@ -47,6 +47,7 @@ struct pcbenv {
     bool gen_on, gen_outstanding;
     int gen_grid;  // workgroups of a refill launch (GEN_MAX_GRID; PCBENV_GEN_GRID overrides, for experiments)
     GenParams gp;
+    unsigned *cursor_snap;  // the cursors as of a fill's snapshot: what k_gen_fill reads (see gen_start_fill)
     hipStream_t gen_stream;
     hipEvent_t ev_snap, ev_fill;
     long long since_waited, since_outstanding;
@@ -291,6 +292,7 @@ extern "C" void pcbenv_destroy(pcbenv *env) {
         hipStreamDestroy(env->gen_stream);
         if (env->gp.gen) hipFree(env->gp.gen);
         if (env->gp.produced) hipFree(env->gp.produced);
+        if (env->cursor_snap) hipFree(env->cursor_snap);
     }
     if (env->state_buf[0]) hipFree(env->state_buf[0]);
     if (env->state_buf[1]) hipFree(env->state_buf[1]);
@@ -533,6 +535,10 @@ static void gen_launch_fill(pcbenv *env, hipStream_t s, bool whole_batch) {
     else hipLaunchKernelGGL(k_gen_fill<64>, dim3(grid), dim3(WAVE), lds, s, env->gp);
 }
 static void gen_start_fill(pcbenv *env, hipStream_t main) {
+    // The fill works from a copy of the published cursors taken in stream order: it learns of a reset only once the launch
+    // that made it has COMPLETED, so a record is never overwritten while a team of a running launch may still be reading it
+    // (an environment's own team publishes its cursor as soon as it has its copy; its feature helper reads the same record).
+    hipMemcpyAsync(env->cursor_snap, env->dp.cursor_pub, 4 * (size_t)env->dp.B, hipMemcpyDeviceToDevice, main);
     hipEventRecord(env->ev_snap, main);
     hipStreamWaitEvent(env->gen_stream, env->ev_snap, 0);
     gen_launch_fill(env, env->gen_stream, false);
@@ -578,7 +584,10 @@ extern "C" int pcbenv_instgen_device_enable(pcbenv *env, const uint32_t *seeds_h
     g.min_h = c.min_component_h; g.max_h = c.max_component_h; g.min_w = c.min_component_w; g.max_w = c.max_component_w;
     g.min_nets = c.min_num_nets; g.max_nets = c.max_num_nets; g.min_ppn = c.min_num_pins_per_net; g.max_ppn = c.max_num_pins_per_net;
     g.net_distribution = c.net_distribution; g.pin_spread = c.pin_spread;  // clipped at create like the reference does
-    g.instStride = d.instStride; g.queue = d.queue; g.cursor_pub = d.cursor_pub;
+    g.instStride = d.instStride; g.queue = d.queue;
+    HIP_TRY(env, hipMalloc((void **)&env->cursor_snap, 4 * (size_t)d.B));
+    HIP_TRY(env, hipMemcpyAsync(env->cursor_snap, d.cursor_pub, 4 * (size_t)d.B, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    g.cursor_pub = env->cursor_snap;
     hipStream_t s = (hipStream_t)stream;
     unsigned *seeds_dev = 0;
     HIP_TRY(env, hipMalloc((void **)&g.gen, sizeof(GenState) * (size_t)d.B));
@@ -688,33 +697,68 @@ extern "C" const uint64_t *pcbenv_mask_bits(const pcbenv *env, int64_t *env_stri
     return (const uint64_t *)(env->dp.state + env->dp.offVm);
 }
 
+// Checkpoint layout: [state blocks, B x stateStride] and, once the on-device generator is enabled,
+// [GenState x B | produced, uint32 x B | the instance queue, Q x B x instStride] behind them.
+static size_t state_section_bytes(const pcbenv *env) { return (size_t)env->dp.stateStride * env->dp.B; }
+static size_t gen_section_bytes(const pcbenv *env) {
+    if (!env->gen_on) return 0;
+    const size_t B = (size_t)env->dp.B;
+    return sizeof(GenState) * B + 4 * B + (size_t)env->dp.instStride * B * (size_t)env->dp.Q;
+}
 extern "C" int64_t pcbenv_state_bytes(const pcbenv *env) {
-    return env ? (int64_t)env->dp.stateStride * env->dp.B : 0;
+    return env ? (int64_t)(state_section_bytes(env) + gen_section_bytes(env)) : 0;
 }
 extern "C" int pcbenv_get_state(pcbenv *env, void *host_dst, void *stream) {
     if (!env || !host_dst) return fail(env, PCBENV_EINVAL, "null argument");
     DEVICE_GUARD(env);
-    const size_t sb = (size_t)env->dp.stateStride * env->dp.B;
-    HIP_TRY(env, hipMemcpyAsync(host_dst, env->dp.state, sb, hipMemcpyDeviceToHost, (hipStream_t)stream));
-    HIP_TRY(env, hipStreamSynchronize((hipStream_t)stream));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t sb = state_section_bytes(env), B = (size_t)env->dp.B;
+    unsigned char *dst = (unsigned char *)host_dst;
+    HIP_TRY(env, hipMemcpyAsync(dst, env->dp.state, sb, hipMemcpyDeviceToHost, s));
+    HIP_TRY(env, hipStreamSynchronize(s));
+    if (env->gen_on) {
+        // The generator's streams, counters and records are part of what a resumed run continues from.  Bring the queue to
+        // its quiescent point first (queue_depth records ahead of every cursor, nothing in flight: the state a restore
+        // re-creates), then copy on the generator's stream, in order behind its kernels.
+        gen_start_fill(env, s);
+        HIP_TRY(env, hipStreamSynchronize(env->gen_stream));
+        env->gen_outstanding = false; env->since_waited = 0; env->since_outstanding = 0;
+        unsigned char *g = dst + sb;
+        HIP_TRY(env, hipMemcpyAsync(g, env->gp.gen, sizeof(GenState) * B, hipMemcpyDeviceToHost, env->gen_stream));
+        HIP_TRY(env, hipMemcpyAsync(g + sizeof(GenState) * B, env->gp.produced, 4 * B, hipMemcpyDeviceToHost, env->gen_stream));
+        HIP_TRY(env, hipMemcpyAsync(g + sizeof(GenState) * B + 4 * B, env->dp.queue, (size_t)env->dp.instStride * B * (size_t)env->dp.Q,
+                                    hipMemcpyDeviceToHost, env->gen_stream));
+        HIP_TRY(env, hipStreamSynchronize(env->gen_stream));
+    }
     return PCBENV_OK;
 }
 extern "C" int pcbenv_set_state(pcbenv *env, const void *host_src, void *stream) {
     if (!env || !host_src) return fail(env, PCBENV_EINVAL, "null argument");
-    if (env->gen_on) return fail(env, PCBENV_ESTATE, "restoring a checkpoint is not supported while the on-device generator runs (its streams are not part of the state)");
     DEVICE_GUARD(env);
-    const size_t sb = (size_t)env->dp.stateStride * env->dp.B;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t sb = state_section_bytes(env), B = (size_t)env->dp.B;
     // The terminal-list marks in a checkpoint refer to lists of the run that wrote it: restored environments are not listed.
     std::vector<unsigned char> blob((const unsigned char *)host_src, (const unsigned char *)host_src + sb);
-    std::vector<unsigned> cur((size_t)env->dp.B);  // the published copy of the queue cursors follows the restored headers
-    for (int i = 0; i < env->dp.B; i++) {
-        EnvHdr *hd = (EnvHdr *)(blob.data() + (size_t)i * env->dp.stateStride);
+    std::vector<unsigned> cur(B);  // the published copy of the queue cursors follows the restored headers
+    for (size_t i = 0; i < B; i++) {
+        EnvHdr *hd = (EnvHdr *)(blob.data() + i * env->dp.stateStride);
         hd->term_seq = 0u;
-        cur[(size_t)i] = hd->qcursor;
+        cur[i] = hd->qcursor;
     }
-    HIP_TRY(env, hipMemcpyAsync(env->dp.state, blob.data(), sb, hipMemcpyHostToDevice, (hipStream_t)stream));
-    HIP_TRY(env, hipMemcpyAsync(env->dp.cursor_pub, cur.data(), 4 * (size_t)env->dp.B, hipMemcpyHostToDevice, (hipStream_t)stream));
-    HIP_TRY(env, hipStreamSynchronize((hipStream_t)stream));
+    if (env->gen_on) {  // nothing of the generator may be in flight while its state is replaced
+        HIP_TRY(env, hipStreamSynchronize(s));
+        HIP_TRY(env, hipStreamSynchronize(env->gen_stream));
+    }
+    HIP_TRY(env, hipMemcpyAsync(env->dp.state, blob.data(), sb, hipMemcpyHostToDevice, s));
+    HIP_TRY(env, hipMemcpyAsync(env->dp.cursor_pub, cur.data(), 4 * B, hipMemcpyHostToDevice, s));
+    if (env->gen_on) {
+        const unsigned char *g = (const unsigned char *)host_src + sb;
+        HIP_TRY(env, hipMemcpyAsync(env->gp.gen, g, sizeof(GenState) * B, hipMemcpyHostToDevice, s));
+        HIP_TRY(env, hipMemcpyAsync(env->gp.produced, g + sizeof(GenState) * B, 4 * B, hipMemcpyHostToDevice, s));
+        HIP_TRY(env, hipMemcpyAsync(env->dp.queue, g + sizeof(GenState) * B + 4 * B, (size_t)env->dp.instStride * B * (size_t)env->dp.Q, hipMemcpyHostToDevice, s));
+        env->gen_outstanding = false; env->since_waited = 0; env->since_outstanding = 0;  // the checkpoint was taken at the quiescent point
+    }
+    HIP_TRY(env, hipStreamSynchronize(s));
     return PCBENV_OK;
 }
 

@@ -331,22 +331,37 @@ class BatchedPlacementEnv:
     # -- checkpoint / resume ------------------------------------------------------------------
     def state_dict(self) -> dict:
         """Library state + observation tensors (host copies).  The reference never serialises env state
-        (SURVEY.md §5); this is what a resumable rollout needs.  The instance queue is reloaded separately."""
+        (SURVEY.md §5); this is what a resumable rollout needs.  With the on-device generator the blob also holds its
+        streams, counters and queued records (a resumed run draws the same instances); a host-fed queue is reloaded
+        separately."""
         n = self._L.pcbenv_state_bytes(self._h)
         buf = np.empty(n, np.uint8)
         _lib.check(self._L.pcbenv_get_state(self._h, buf.ctypes.data, self._stream()), self._h)
-        d = {"state": buf, "reward": self.reward.cpu(), "done": self.done.cpu(), "info": self.info_raw.cpu()}
+        stride = C.c_int64()
+        self._L.pcbenv_mask_bits(self._h, C.byref(stride))
+        nb = stride.value * self.num_envs  # the state blocks; the generator's section (if any) follows them
+        d = {"state": buf[:nb], "generator": buf[nb:], "reward": self.reward.cpu(), "done": self.done.cpu(), "info": self.info_raw.cpu(),
+             "last_done": self._last_done.cpu(), "slot": self.slot, "device_instances": self.device_instances}
         d.update({"obs/" + k: v.cpu() for k, v in self.obs.items()})
         return d
 
     def load_state_dict(self, d: dict):
-        buf = np.ascontiguousarray(d["state"], np.uint8)
+        buf = np.ascontiguousarray(np.concatenate([np.asarray(d["state"], np.uint8).ravel(), np.asarray(d.get("generator", ()), np.uint8).ravel()]))
+        if bool(d.get("device_instances", False)) != self.device_instances:
+            raise ValueError("the checkpoint was taken with" + ("" if d.get("device_instances") else "out") + " the on-device generator: "
+                             "call enable_device_instances() on this environment " + ("first" if d.get("device_instances") else "only after restoring"))
         if buf.size != self._L.pcbenv_state_bytes(self._h):
             raise ValueError("state size does not match this environment")
+        if "slot" in d:
+            self.select_slot(int(d["slot"]))
         _lib.check(self._L.pcbenv_set_state(self._h, buf.ctypes.data, self._stream()), self._h)
         self.reward.copy_(d["reward"]); self.done.copy_(d["done"]); self.info_raw.copy_(d["info"])
         for k, v in self.obs.items():
             v.copy_(d["obs/" + k])
+        # `done` of the latest step: restored into the selected slot's tensor (where reset_done() will look)
+        self._last_done = self.done
+        if "last_done" in d:
+            self._last_done.copy_(d["last_done"])
 
     def mask_bits(self) -> torch.Tensor:
         """Bit-packed legal-action mask, int64 [B, 2, H, ceil(W/64)] (a copy; bit y of word [b, o, x, y // 64])."""

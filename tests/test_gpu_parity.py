@@ -282,6 +282,75 @@ def test_state_dict_roundtrip_and_mask_bits():
     env.close()
 
 
+@pytest.mark.parametrize("name,B", [("c3", 64), ("c4", 32), ("c2", 64)])
+def test_state_dict_roundtrip_with_the_device_generator(name, B):
+    """Checkpoint / resume with a fresh on-device instance at every reset (the reference's reset() semantics): the blob
+    carries the generator's two MT19937 streams per environment, its counters and the queued records, so the resumed run
+    -- in the same handle, and in a fresh one -- replays more than three episodes bit for bit, observations included,
+    and a second snapshot taken after the replay equals the one the original run would take."""
+    cfg = named_config(name)
+    L = cfg.max_num_components
+    T = 3 * L + 5
+
+    def run(env, t0):
+        out = []
+        for t in range(t0, t0 + T):
+            o, r, d, _, a = env.rollout_step(t)
+            out.append({"r": r.cpu().numpy().copy(), "d": d.cpu().numpy().copy(), "a": a.cpu().numpy().copy(),
+                        **{k: v.cpu().numpy().copy() for k, v in o.items()}})
+        return out
+
+    env = BatchedPlacementEnv(cfg, B, queue_depth=6, run_seed=21, auto_reset=True)
+    env.enable_device_instances()
+    env.reset()
+    for t in range(L + 3):
+        env.rollout_step(t)
+    snap = env.state_dict()
+    assert snap["device_instances"] and snap["state"].size + snap["generator"].size == env._L.pcbenv_state_bytes(env._h) and snap["generator"].size > 0
+    want = run(env, L + 3)
+    after = env.state_dict()
+    env.load_state_dict(snap)
+    other = BatchedPlacementEnv(cfg, B, queue_depth=6, run_seed=99, auto_reset=True)  # other seeds: everything must come from the blob
+    with pytest.raises(ValueError):
+        other.load_state_dict(snap)  # the generator has to be enabled first
+    other.enable_device_instances()
+    other.reset()
+    other.load_state_dict(snap)
+    other.run_seed = env.run_seed  # (the key of the action sampler; the instance streams were seeded from 99 above)
+    for e in (env, other):
+        got = run(e, L + 3)
+        for t, (g, w) in enumerate(zip(got, want)):
+            for k in w:
+                a, b = (g[k].view(np.uint64), w[k].view(np.uint64)) if g[k].dtype == np.float64 else (g[k], w[k])
+                assert np.array_equal(a, b), (t, k)
+        again = e.state_dict()
+        assert np.array_equal(again["state"], after["state"]) and np.array_equal(again["generator"], after["generator"])
+        assert e.device_instance_errors() == 0
+        e.close()
+
+
+def test_refused_host_load_leaves_the_generator_queue_alone():
+    """Once the on-device generator owns the queue, pcbenv_load_instances is refused BEFORE anything is copied (the
+    refusal used to come after the copy into the slot)."""
+    from pcbenv import _lib
+    cfg = named_config("c3")
+    B = 32
+    env = BatchedPlacementEnv(cfg, B, queue_depth=4, run_seed=5, auto_reset=True)
+    packed = env.generate_instances()      # host records in every slot
+    env.enable_device_instances()          # ... replaced by the generator's
+    before = [env.queued_instances(s) for s in range(4)]
+    assert not np.array_equal(before[0], packed[0][::-1])
+    junk = np.ascontiguousarray(packed[0][::-1])
+    for call in (lambda: env.load_packed(junk, 0), lambda: env.generate_instances(), lambda: env.refill_slot(1)):
+        with pytest.raises(RuntimeError):
+            call()
+    rc = env._L.pcbenv_load_instances(env._h, None, B, 0, junk.ctypes.data, env._stream())  # straight through the C ABI
+    assert rc == _lib.PCBENV_ESTATE
+    for s in range(4):
+        assert np.array_equal(env.queued_instances(s), before[s]), s
+    env.close()
+
+
 def test_rollout_driver_matches_oracle_returns():
     """Trajectory buffers on device; per-episode returns of the uniform random policy == the oracle's on the
     recorded action stream (counterpart of the reference's simulate() loop)."""

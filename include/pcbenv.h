@@ -128,6 +128,20 @@ typedef struct pcbenv_buffers {
     uint8_t *mask_rows;             /* [B, O, H] = max over y of action_mask          optional, all kinds */
 } pcbenv_buffers;
 
+/* Compact feature tensors for the trajectory layout (optional, pcbenv_bind_compact_features): the same values as the
+ * float64 feature tensors above in the narrowest integer type that holds them -- every element is a small integer
+ * except all_components_feature[..., 4] = area / (H * W), which is carried as its numerator h * w (divide by H * W in
+ * float64 to get the reference's value bit for bit).  A rollout that keeps every step's observation writes 8x fewer
+ * feature bytes this way (c3: 23.8 KB -> 3.0 KB per env-step).  Layout [num_slots, B, ...] like the other tensors;
+ * a null pointer means "not wanted".  */
+typedef struct pcbenv_compact_features {
+    int16_t *all_components_feature; /* [B, C, F]: h, w, x, y (-1 unplaced), h * w, (spatial) pin ids padded with -1    */
+    uint8_t *placement_mask;         /* [B, C]  the reference's codes 0..3 (rect: 0 / 1)                                 */
+    uint8_t *component_mask;         /* [B, C]  rect                                                                     */
+    int8_t *all_pins_num_feature;    /* [B, R, 4]  rel_x, rel_y, abs_x, abs_y (-1 unplaced; coordinates < 128)            */
+    int8_t *all_pins_cat_feature;    /* [B, R, Wc] net (, component); spatial: last row -1                                */
+} pcbenv_compact_features;
+
 /* Instance wire format (host memory), one record of pcbenv_instance_stride() bytes:
  *   int32 num_components, num_nets, num_pins, reserved                      (16 bytes)
  *   max_num_components x { uint8 h, w; uint8 pad[6] }                       (8 bytes each)
@@ -180,6 +194,11 @@ int pcbenv_set_option(pcbenv *env, int32_t option, int64_t value);
  * pcbenv_bind_buffers(env, b) == pcbenv_bind_buffers_slots(env, b, 1). */
 int pcbenv_bind_buffers_slots(pcbenv *env, const pcbenv_buffers *buffers, int32_t num_slots);
 int pcbenv_select_slot(pcbenv *env, int32_t slot);
+
+/* Binds (or, with NULL, unbinds) compact feature tensors next to the buffers of pcbenv_bind_buffers_slots; needs the
+ * trajectory layout (num_slots > 1, where every step writes every bound tensor whole).  Float64 feature pointers left
+ * NULL in pcbenv_buffers are then simply not produced. */
+int pcbenv_bind_compact_features(pcbenv *env, const pcbenv_compact_features *features);
 
 /* Copies n packed instance records (host memory) into queue slot `slot`
  * (0 <= slot < queue_depth) of environments env_ids[0..n) (env_ids == NULL:

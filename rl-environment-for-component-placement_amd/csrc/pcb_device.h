@@ -32,6 +32,9 @@ struct DevParams {
     int ldsHfWords;                         // 64-bit words of the fold scratch / row-membership bit map at ldsHf (sized by need)
     unsigned char *state, *queue;
     pcbenv_buffers buf;
+    pcbenv_compact_features cbuf;           // compact feature tensors of the trajectory layout (all null unless bound)
+    // episode-constant observation bytes per environment (spatial, trajectory layout; pcb_observe.h feat_cache_*)
+    unsigned char *feat_cache; unsigned *feat_cache_tag; int featCacheStride, featCacheCg;
     unsigned long long *dbg;                // diagnostic build only (-DPCBENV_STAMPS): [B][32] s_memtime stamps
     int stream_stores;                      // observation stores bypass the caches (`nt`): see STORE16.  (Behind the
                                             // fields every wave loads first, so that their kernarg offsets stay put.)

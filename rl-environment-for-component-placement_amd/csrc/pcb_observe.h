@@ -225,12 +225,10 @@ static __device__ inline void build_pin_tables(const DevParams &p, Lds &l, int l
 }
 // S:1677-1697 draw_components from the tables above: byte (cell, ch) = ch == 0 ? component exists : net ch-1 has a
 // pin on the cell; each byte written once.
-static __device__ inline void emit_component_grid(const DevParams &p, Lds &l, int row, int lane) {
-    if (!p.buf.component_grid) return;
+static __device__ inline void emit_component_grid_to(const DevParams &p, Lds &l, unsigned char *cg, int lane) {
     const PinTables t = pin_tables(p, l);
     const int nc = l.hdr->ncomp;
     const int cells = p.mh * p.mw, cgsz = cells * p.K, total = p.C * cgsz;
-    unsigned char *cg = p.buf.component_grid + (size_t)row * total;
     if ((total & 15) == 0 && (((uintptr_t)cg) & 15) == 0) {
         const ObsDst d = obs_dst(cg, total);
         for (int c16 = lane; c16 < total / 16; c16 += NT) {
@@ -254,13 +252,160 @@ static __device__ inline void emit_component_grid(const DevParams &p, Lds &l, in
     }
 }
 
+static __device__ inline void emit_component_grid(const DevParams &p, Lds &l, int row, int lane) {
+    if (!p.buf.component_grid) return;
+    emit_component_grid_to(p, l, p.buf.component_grid + (size_t)row * p.C * p.mh * p.mw * p.K, lane);
+}
+
+// The episode-constant part of a spatial environment's trajectory slot, kept per environment in library memory so that a
+// step of the trajectory layout copies it instead of rebuilding the pin tables: [compact all_components_feature, C x F
+// int16 with x = y = -1 | component_grid].  Written by the reset that starts the episode (tagged with the episode number;
+// a restored checkpoint invalidates the tags), used by steps whose slot takes no float64 all_components_feature.
+static __device__ inline bool feat_cache_valid(const DevParams &p, const Lds &l, int e) {
+    return p.feat_cache && !p.buf.all_components_feature && p.feat_cache_tag[e] == l.hdr->episode;
+}
+static __device__ inline void feat_cache_fill(const DevParams &p, Lds &l, int e, int lane) {  // spatial, build_pin_tables() has run
+    if (!p.feat_cache) return;
+    unsigned char *base = p.feat_cache + (size_t)e * p.featCacheStride;
+    const PinTables t = pin_tables(p, l);
+    const int nc = l.hdr->ncomp;
+    short *cf = (short *)base;
+    int c = lane / p.F, k = lane - c * p.F;
+    const int dc = NT / p.F, dk = NT - dc * p.F;
+    for (int i = lane; i < p.C * p.F; i += NT) {
+        int v = 0;
+        if (c < nc) {
+            const CompRec cr = l.comps[c];
+            if (k == 0) v = cr.h; else if (k == 1) v = cr.w; else if (k == 2 || k == 3) v = -1;
+            else if (k == 4) v = cr.h * cr.w;
+            else { const unsigned id = t.pid[c * p.mp + k - 5]; v = id == 0xFFFFu ? -1 : (int)id; }
+        }
+        cf[i] = (short)v;
+        c += dc; k += dk;
+        if (k >= p.F) { k -= p.F; c++; }
+    }
+    emit_component_grid_to(p, l, base + p.featCacheCg, lane);
+    if (lane == 0) p.feat_cache_tag[e] = l.hdr->episode;
+}
+// A step's copy: compact all_components_feature with the components' current positions patched in, component_grid as is.
+static __device__ inline void feat_cache_emit(const DevParams &p, Lds &l, int e, int row, int lane) {
+    const unsigned char *base = p.feat_cache + (size_t)e * p.featCacheStride;
+    if (p.cbuf.all_components_feature) {
+        const short *src = (const short *)base;
+        short *cf = p.cbuf.all_components_feature + (size_t)row * p.C * p.F;
+        int c = lane / p.F, k = lane - c * p.F;
+        const int dc = NT / p.F, dk = NT - dc * p.F;
+        for (int i = lane; i < p.C * p.F; i += NT) {
+            short v = src[i];
+            if (k == 2 && c < l.hdr->ncomp) v = l.comps[c].px;
+            if (k == 3 && c < l.hdr->ncomp) v = l.comps[c].py;
+            cf[i] = v;
+            c += dc; k += dk;
+            if (k >= p.F) { k -= p.F; c++; }
+        }
+    }
+    if (p.buf.component_grid) {
+        const int total = p.C * p.mh * p.mw * p.K;
+        unsigned char *cg = p.buf.component_grid + (size_t)row * total;
+        const uint4 *src = (const uint4 *)(base + p.featCacheCg);
+        if ((total & 15) == 0 && (((uintptr_t)cg) & 15) == 0) {
+            const ObsDst d = obs_dst(cg, total);
+            for (int c16 = lane; c16 < total / 16; c16 += NT) STORE16_dyn(d, (unsigned)c16 * 16u, src[c16], p.stream_stores);
+        } else {
+            for (int i = lane; i < total; i += NT) cg[i] = base[p.featCacheCg + i];
+        }
+    }
+}
+
 // Every float64 feature tensor of environment `row`, whole, from the state in LDS -- each element written exactly
 // once (no write-after-write inside the launch).  Used when the destination holds nothing of this environment:
 // the trajectory layout (num_slots > 1), where every step lands in a fresh slot.  all_components_feature
 // (R:60-79, S:203-239), placement / component masks (S:1445-1451, :1592-1602; R:275-298), pin features
 // (P:72-103 / S:70-104, quirk Q1 for the pin env, S:1520 last row).  Spatial: build_pin_tables() must have run.
-template <int KIND> static __device__ inline void emit_features_full(const DevParams &p, Lds &l, int row, int lane) {
+// The compact twins of the float64 feature tensors (pcbenv_compact_features): same values, same "each element written
+// exactly once" discipline, 2 / 1 bytes per element.  Spatial: build_pin_tables() must have run.
+template <int KIND> static __device__ inline void emit_features_compact(const DevParams &p, Lds &l, int row, int lane, bool comp_from_cache = false) {
+    const int nc = l.hdr->ncomp, np = l.hdr->npins, cur = l.hdr->cur;
+    if (p.cbuf.all_components_feature && !comp_from_cache) {
+        const PinTables t = pin_tables(p, l);
+        short *cf = p.cbuf.all_components_feature + (size_t)row * p.C * p.F;
+        int c = lane / p.F, k = lane - c * p.F;
+        const int dc = NT / p.F, dk = NT - dc * p.F;
+        for (int i = lane; i < p.C * p.F; i += NT) {
+            int v = 0;
+            if (c < nc) {
+                const CompRec cr = l.comps[c];
+                if (k == 0) v = cr.h; else if (k == 1) v = cr.w; else if (k == 2) v = cr.px; else if (k == 3) v = cr.py;
+                else if (k == 4) v = cr.h * cr.w;  // the numerator of area / (H * W)
+                else {
+                    const unsigned id = KIND == PCBENV_SPATIAL ? t.pid[c * p.mp + k - 5] : 0xFFFFu;
+                    v = id == 0xFFFFu ? -1 : (int)id;
+                }
+            }
+            cf[i] = (short)v;
+            c += dc; k += dk;
+            if (k >= p.F) { k -= p.F; c++; }
+        }
+    }
+    if (p.cbuf.placement_mask) {
+        unsigned char *pm = p.cbuf.placement_mask + (size_t)row * p.C;
+        for (int c = lane; c < p.C; c += NT) {
+            const bool placed = c < nc && l.comps[c].px >= 0;
+            pm[c] = (unsigned char)(KIND == PCBENV_RECT ? (placed ? 1 : 0) : (c >= nc ? 0 : placed ? 2 : c == cur ? 3 : 1));
+        }
+    }
+    if (KIND == PCBENV_RECT && p.cbuf.component_mask) {
+        unsigned char *cm = p.cbuf.component_mask + (size_t)row * p.C;
+        for (int c = lane; c < p.C; c += NT) cm[c] = c < nc ? 1 : 0;
+    }
+    if (KIND == PCBENV_PIN || KIND == PCBENV_SPATIAL) {
+        // one 32-bit word per pin row of all_pins_num_feature, one byte / 16-bit word per row of all_pins_cat_feature
+        unsigned *fn = (unsigned *)p.cbuf.all_pins_num_feature; if (fn) fn += (size_t)row * p.pinRows;
+        signed char *fc = p.cbuf.all_pins_cat_feature ? p.cbuf.all_pins_cat_feature + (size_t)row * p.pinRows * p.catW : 0;
+        if (!fn && !fc) return;
+        auto quad = [](const PinRec &pr) { return (unsigned)pr.rel_x | ((unsigned)pr.rel_y << 8) | ((unsigned)(unsigned char)pr.abs_x << 16) | ((unsigned)(unsigned char)pr.abs_y << 24); };
+        if (KIND == PCBENV_SPATIAL) {  // row = global pin id: rows 0..np-1 belong to pins, the others are constant
+            for (int r = np + lane; r < p.pinRows; r += NT) {
+                if (fn) fn[r] = 0u;
+                if (fc) ((unsigned short *)fc)[r] = r == p.pinRows - 1 ? 0xFFFFu : 0u;  // (net, component) of a row as one 16-bit word
+            }
+            for (int q = lane; q < np; q += NT) {
+                const PinRec pr = l.pins[q];
+                const int r = pr.id & PIN_ID_MASK;
+                if (fn) fn[r] = quad(pr);
+                if (fc) ((unsigned short *)fc)[r] = (unsigned short)(pr.net | (pr.comp << 8));
+            }
+        } else {  // pin env: rows [component, pin_id] through the membership bit map (always large enough for this kind)
+            u64 *rowbits = l.hf;
+            lds_sync();
+            for (int i = lane; i < p.ldsHfWords; i += NT) rowbits[i] = 0ull;
+            lds_sync();
+            for (int q = lane; q < np; q += NT) {
+                const PinRec pr = l.pins[q];
+                const int r = pr.comp * p.mp + (pr.id & PIN_ID_MASK);
+                atomicOr((unsigned long long *)&rowbits[r >> 6], 1ull << (r & 63));
+            }
+            lds_sync();
+            for (int r = lane; r < p.pinRows; r += NT) {
+                if ((rowbits[r >> 6] >> (r & 63)) & 1ull) continue;
+                if (fn) fn[r] = 0u;
+                if (fc) fc[r] = 0;
+            }
+            for (int q = lane; q < np; q += NT) {
+                const PinRec pr = l.pins[q];
+                if (pr.id & PIN_LOSER) continue;  // quirk Q1: the last pin with this [component, pin_id] owns the row
+                const int r = pr.comp * p.mp + (pr.id & PIN_ID_MASK);
+                if (fn) fn[r] = quad(pr);
+                if (fc) fc[r] = (signed char)pr.net;
+            }
+            lds_sync();
+        }
+    }
+}
+
+template <int KIND> static __device__ inline void emit_features_full(const DevParams &p, Lds &l, int row, int lane, bool comp_from_cache = false) {
     if (KIND == PCBENV_SQUARE) return;
+    emit_features_compact<KIND>(p, l, row, lane, comp_from_cache);
     const int nc = l.hdr->ncomp, np = l.hdr->npins, cur = l.hdr->cur;
     if (p.buf.all_components_feature) {
         const PinTables t = pin_tables(p, l);

@@ -247,6 +247,7 @@ template <int KIND, int WW, bool TRAJ> static __device__ inline void reset_env(c
         if (KIND == PCBENV_SPATIAL && feats) {
             if (p.buf.pin_grid) emit_zero(p.buf.pin_grid + (size_t)row * HW * p.K, (long long)HW * p.K, lane, p.stream_stores);  // S:1504
             emit_component_grid(p, l, row, lane);  // S:1677-1697 draw_components (unrotated rel coords; channel 0 == 1)
+            if (full) feat_cache_fill(p, l, e, lane);  // what the steps of this episode copy into their slots
         }
     }
     lds_sync();

@@ -124,9 +124,14 @@ static __device__ __forceinline__ void transition(const DevParams &p, Lds &l, in
             const int r0 = inc ? x : 0, r1 = inc ? min(x + ph, H) : H;
             const bool skip_emit = auto_reset && KIND != PCBENV_SQUARE && l.hdr->cur < 0;
             if (TRAJ && full && !skip_emit) {  // every float64 tensor of the fresh slot, and the episode-constant component_grid
-                if (KIND == PCBENV_SPATIAL) build_pin_tables(p, l, lane);
-                emit_features_full<KIND>(p, l, row, lane);
-                if (KIND == PCBENV_SPATIAL) { emit_component_grid(p, l, row, lane); lds_sync(); }
+                if (KIND == PCBENV_SPATIAL && feat_cache_valid(p, l, e)) {  // ... copied from the episode's cache where there is one
+                    emit_features_full<KIND>(p, l, row, lane, true);
+                    feat_cache_emit(p, l, e, row, lane);
+                } else {
+                    if (KIND == PCBENV_SPATIAL) build_pin_tables(p, l, lane);
+                    emit_features_full<KIND>(p, l, row, lane);
+                    if (KIND == PCBENV_SPATIAL) { emit_component_grid(p, l, row, lane); lds_sync(); }
+                }
             }
             const bool any = mask_and_emit<KIND, WW>(p, l, row, lane, !skip_emit, r0, r1);
             STAMP(23);

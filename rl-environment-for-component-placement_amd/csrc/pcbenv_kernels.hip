@@ -301,6 +301,8 @@ extern "C" void pcbenv_destroy(pcbenv *env) {
     if (env->dp.term_list) hipFree(env->dp.term_list);
     if (env->dp.term_cnt) hipFree(env->dp.term_cnt);
     if (env->dp.term_arrive) hipFree(env->dp.term_arrive);
+    if (env->dp.feat_cache) hipFree(env->dp.feat_cache);
+    if (env->dp.feat_cache_tag) hipFree(env->dp.feat_cache_tag);
     if (env->term_seen_host) hipHostFree(env->term_seen_host);
     if (env->scratch) hipFree(env->scratch);
     delete env;
@@ -360,8 +362,33 @@ extern "C" int pcbenv_bind_buffers_slots(pcbenv *env, const pcbenv_buffers *b, i
     if (!is_pin_kind(k)) { env->dp.buf.all_pins_num_feature = 0; env->dp.buf.all_pins_cat_feature = 0; env->dp.buf.info = 0; }
     if (k != PCBENV_RECT) env->dp.buf.component_mask = 0;
     if (k == PCBENV_SQUARE) { env->dp.buf.all_components_feature = 0; env->dp.buf.placement_mask = 0; }
+    if (k == PCBENV_SPATIAL && num_slots > 1 && !env->dp.feat_cache) {  // the episode-constant bytes a trajectory step copies
+        DevParams &d = env->dp;
+        d.featCacheCg = align16(2ll * d.C * d.F);
+        d.featCacheStride = align16((long long)d.featCacheCg + (long long)d.C * d.mh * d.mw * d.K);
+        DEVICE_GUARD(env);
+        if (hipMalloc((void **)&d.feat_cache, (size_t)d.featCacheStride * d.B) != hipSuccess || hipMalloc((void **)&d.feat_cache_tag, 4 * (size_t)d.B) != hipSuccess)
+            return fail(env, PCBENV_EHIP, "hipMalloc failed");
+    }
+    if (env->dp.feat_cache_tag) hipMemset(env->dp.feat_cache_tag, 0xFF, 4 * (size_t)env->dp.B);  // no episode has that number: nothing cached yet
     env->dp.bind_gen += 1;  // feature tensors of these buffers are uninitialised: the next reset of each env fills them
+    memset(&env->dp.cbuf, 0, sizeof(env->dp.cbuf));  // compact tensors belong to a binding: bind them again
     env->bound = true;
+    return PCBENV_OK;
+}
+
+extern "C" int pcbenv_bind_compact_features(pcbenv *env, const pcbenv_compact_features *f) {
+    if (!env) return fail(0, PCBENV_EINVAL, "null handle");
+    if (!env->bound) return fail(env, PCBENV_ESTATE, "pcbenv_bind_buffers has not been called");
+    memset(&env->dp.cbuf, 0, sizeof(env->dp.cbuf));
+    if (!f) return PCBENV_OK;
+    if (env->dp.num_slots < 2) return fail(env, PCBENV_EINVAL, "compact feature tensors need the trajectory layout (pcbenv_bind_buffers_slots with num_slots > 1)");
+    if (env->dp.H > 128 || env->dp.W > 128) return fail(env, PCBENV_ELIMIT, "coordinates do not fit the compact pin tensors");
+    env->dp.cbuf = *f;
+    const int k = env->cfg.kind;
+    if (!is_pin_kind(k)) { env->dp.cbuf.all_pins_num_feature = 0; env->dp.cbuf.all_pins_cat_feature = 0; }
+    if (k != PCBENV_RECT) env->dp.cbuf.component_mask = 0;
+    if (k == PCBENV_SQUARE) memset(&env->dp.cbuf, 0, sizeof(env->dp.cbuf));
     return PCBENV_OK;
 }
 
@@ -442,13 +469,11 @@ static int dispatch_step(pcbenv *env, int *actions, int fmt, int sampled, u64 se
     a.num_steps = num_steps; a.threads = env->threads; a.stream = s;
     // lean build (in-place layout, one transition, store policy compiled in) or the trajectory / rollout build
     a.traj = d.num_slots > 1 || num_steps > 1;
-    // A persistent rollout into the trajectory layout writes min(num_steps, num_slots) slots per launch, none of which is
-    // read before the launch ends: the policy is chosen on what the LAUNCH writes (in place, the steps of a rollout
-    // overwrite the same lines and the per-transition choice of pcbenv_create stands).
-    if (a.traj && d.num_slots > 1) {
-        const long long slots = num_steps < d.num_slots ? num_steps : d.num_slots;
-        d.stream_stores = env->cell_bytes_per_env * d.B * slots > env->stream_threshold;
-    }
+    // The trajectory layout cycles through num_slots slots: the store policy is chosen on the bytes of all of them (a slot is
+    // next written num_slots steps later; one launch per step into a [17, B, ...] trajectory measured + 14 % at c3, + 3 % at
+    // c4 with streaming stores).  In place, the steps overwrite the same lines and the per-transition choice of
+    // pcbenv_create stands.
+    if (a.traj && d.num_slots > 1) d.stream_stores = env->cell_bytes_per_env * d.B * d.num_slots > env->stream_threshold;
     a.routes = is_pin_kind(env->cfg.kind) && env->cfg.reward_type != PCBENV_REWARD_CENTROID;
     if (++env->seq == 0u) env->seq = 1u;  // 0 is "not listed" in the marks
     d.seq = env->seq;
@@ -751,6 +776,7 @@ extern "C" int pcbenv_set_state(pcbenv *env, const void *host_src, void *stream)
     }
     HIP_TRY(env, hipMemcpyAsync(env->dp.state, blob.data(), sb, hipMemcpyHostToDevice, s));
     HIP_TRY(env, hipMemcpyAsync(env->dp.cursor_pub, cur.data(), 4 * B, hipMemcpyHostToDevice, s));
+    if (env->dp.feat_cache_tag) HIP_TRY(env, hipMemsetAsync(env->dp.feat_cache_tag, 0xFF, 4 * B, s));  // the cached bytes are another episode's
     if (env->gen_on) {
         const unsigned char *g = (const unsigned char *)host_src + sb;
         HIP_TRY(env, hipMemcpyAsync(env->gp.gen, g, sizeof(GenState) * B, hipMemcpyHostToDevice, s));

@@ -16,7 +16,7 @@ ABI_VERSION = 3
 OPT_STREAM_THRESHOLD_BYTES, OPT_TERMINAL_TEAMS, OPT_GEN_GRID, OPT_GEN_LANES = 1, 2, 3, 4
 
 EXPORTS = ("pcbenv_abi_version", "pcbenv_create", "pcbenv_destroy", "pcbenv_last_error",
-           "pcbenv_instance_stride", "pcbenv_max_total_pins", "pcbenv_set_option", "pcbenv_bind_buffers", "pcbenv_bind_buffers_slots", "pcbenv_select_slot",
+           "pcbenv_instance_stride", "pcbenv_max_total_pins", "pcbenv_set_option", "pcbenv_bind_buffers", "pcbenv_bind_buffers_slots", "pcbenv_bind_compact_features", "pcbenv_select_slot",
            "pcbenv_load_instances", "pcbenv_reset", "pcbenv_step", "pcbenv_sample_actions", "pcbenv_step_sampled", "pcbenv_rollout_sampled",
            "pcbenv_mask_bits", "pcbenv_state_bytes", "pcbenv_get_state", "pcbenv_set_state", "pcbenv_queue_cursors",
            "pcbenv_instgen_device_enable", "pcbenv_instgen_device_status", "pcbenv_get_instances",
@@ -40,6 +40,13 @@ BUFFER_FIELDS = ("grid", "action_mask", "pin_grid", "component_grid", "all_compo
 
 class PcbenvBuffers(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in BUFFER_FIELDS]
+
+
+COMPACT_FIELDS = ("all_components_feature", "placement_mask", "component_mask", "all_pins_num_feature", "all_pins_cat_feature")
+
+
+class PcbenvCompactFeatures(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in COMPACT_FIELDS]
 
 
 _lib = None
@@ -67,6 +74,7 @@ def load():
     L.pcbenv_bind_buffers.argtypes = [C.c_void_p, C.POINTER(PcbenvBuffers)]
     L.pcbenv_bind_buffers_slots.argtypes = [C.c_void_p, C.POINTER(PcbenvBuffers), C.c_int32]
     L.pcbenv_select_slot.argtypes = [C.c_void_p, C.c_int32]
+    L.pcbenv_bind_compact_features.argtypes = [C.c_void_p, C.POINTER(PcbenvCompactFeatures)]
     L.pcbenv_load_instances.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     L.pcbenv_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.pcbenv_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]

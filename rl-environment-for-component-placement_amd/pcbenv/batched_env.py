@@ -21,6 +21,24 @@ from .config import EnvConfig, KIND_PIN, KIND_RECT, KIND_SPATIAL, KIND_SQUARE
 from .instances import Instance, InstanceStream, env_seed, pack_instances
 
 
+FEATURE_KEYS = ("all_components_feature", "placement_mask", "component_mask", "all_pins_num_feature", "all_pins_cat_feature")
+COMPACT_DTYPES = {"all_components_feature": torch.int16, "placement_mask": torch.uint8, "component_mask": torch.uint8,
+                  "all_pins_num_feature": torch.int8, "all_pins_cat_feature": torch.int8}
+
+
+def expand_compact_features(cfg: EnvConfig, compact: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Compact feature tensors (pcbenv_compact_features: int16 / int8 / uint8) -> the reference's float64 tensors, bit
+    for bit: every element is a small integer except all_components_feature[..., 4], carried as h * w and divided by
+    H * W here in float64 -- the one IEEE division the reference does (`area / grid_area`, S:203-239)."""
+    out = {}
+    for k, t in compact.items():
+        f = t.to(torch.float64)
+        if k == "all_components_feature":
+            f[..., 4] = f[..., 4] / float(cfg.height * cfg.width)
+        out[k] = f
+    return out
+
+
 def obs_spec(cfg: EnvConfig) -> Dict[str, tuple]:
     """key -> (shape without batch dim, torch dtype); keys and shapes are the reference's."""
     H, W, k = cfg.height, cfg.width, cfg.kind
@@ -60,12 +78,18 @@ class BatchedPlacementEnv:
     def __init__(self, cfg: EnvConfig, num_envs: int, device="cuda:0", queue_depth: int = 1,
                  run_seed: int = 0, first_env_index: int = 0, incremental_obs: bool = False,
                  auto_reset: bool = False, threads_per_env: int = 0,
-                 mask_marginals: bool = False, num_slots: int = 1, options: Optional[Dict[str, int]] = None):
+                 mask_marginals: bool = False, num_slots: int = 1, options: Optional[Dict[str, int]] = None,
+                 compact_features: bool = False, allocator=None):
         """num_slots > 1: trajectory layout -- every output tensor is allocated `[num_slots, B, ...]` (`self.traj`,
         `self.traj_reward`, ...), `select_slot(s)` chooses the slot the next reset / step writes and `self.obs`,
         `self.reward`, `self.done`, `self.info_raw` are views of that slot (pcbenv_bind_buffers_slots).
         options: tuning knobs of the handle, `pcbenv_set_option` (include/pcbenv.h): "stream_threshold_bytes",
-        "terminal_teams", "gen_grid", "gen_lanes" -- none changes a result."""
+        "terminal_teams", "gen_grid", "gen_lanes" -- none changes a result.
+        compact_features (trajectory layout only): the feature tensors are kept as int16 / int8 / uint8
+        (`pcbenv_bind_compact_features`: 8x fewer feature bytes per step) under the same keys of `traj` / `obs`;
+        `obs_f64()` / `expand_compact_features` give the reference's float64 tensors, bit for bit.
+        allocator: `f(name, shape, dtype) -> zero-filled device tensor` for the observation tensors (default torch.zeros);
+        lets a caller place them (tools/c5_modes.py studies where the big cell tensors should sit)."""
         cfg.validate()
         self.cfg, self.num_envs, self.queue_depth = cfg, int(num_envs), int(queue_depth)
         self.run_seed, self.first_env_index = int(run_seed), int(first_env_index)
@@ -90,9 +114,14 @@ class BatchedPlacementEnv:
             self.set_option(name, value)
         B = self.num_envs
         S = self.num_slots = int(num_slots)
+        self.compact_features = bool(compact_features)
+        if self.compact_features and S < 2:
+            raise ValueError("compact_features needs the trajectory layout (num_slots > 1)")
+        alloc = allocator or (lambda name, shape, dtype: torch.zeros(shape, dtype=dtype, device=self.device))
         with torch.cuda.device(self.device):
             self.traj: Dict[str, torch.Tensor] = {
-                k: torch.zeros((S, B) + shape, dtype=dt, device=self.device) for k, (shape, dt) in obs_spec(cfg).items()}
+                k: alloc(k, (S, B) + shape, COMPACT_DTYPES[k] if self.compact_features and k in FEATURE_KEYS else dt)
+                for k, (shape, dt) in obs_spec(cfg).items()}
             self.traj_reward = torch.zeros((S, B), dtype=torch.float64, device=self.device)
             self.traj_done = torch.zeros((S, B), dtype=torch.uint8, device=self.device)
             self.traj_info = torch.full((S, B, 2), float("nan"), dtype=torch.float64, device=self.device)
@@ -114,8 +143,16 @@ class BatchedPlacementEnv:
                 t = self.traj_marginals.get("orientation")
             elif name == "mask_rows":
                 t = self.traj_marginals.get("rows")
+            if self.compact_features and name in FEATURE_KEYS:
+                t = None  # not produced in float64: the compact twin is bound below
             setattr(bufs, name, t.data_ptr() if t is not None else None)
         _lib.check(self._L.pcbenv_bind_buffers_slots(self._h, C.byref(bufs), S), self._h)
+        if self.compact_features:
+            cb = _lib.PcbenvCompactFeatures()
+            for name in _lib.COMPACT_FIELDS:
+                t = self.traj.get(name)
+                setattr(cb, name, t.data_ptr() if t is not None else None)
+            _lib.check(self._L.pcbenv_bind_compact_features(self._h, C.byref(cb)), self._h)
         self.slot = -1
         self.select_slot(0)
         self._last_done = self.done  # `done` of the latest step (it may live in another slot than the selected one)
@@ -156,6 +193,16 @@ class BatchedPlacementEnv:
         self.obs: Dict[str, torch.Tensor] = {k: v[slot] for k, v in self.traj.items()}
         self.reward, self.done, self.info_raw = self.traj_reward[slot], self.traj_done[slot], self.traj_info[slot]
         self.mask_marginals = {k: v[slot] for k, v in self.traj_marginals.items()}
+
+    def obs_f64(self, slot: Optional[int] = None) -> Dict[str, torch.Tensor]:
+        """The observation of `slot` (default: the selected one) with the feature tensors in the reference's float64
+        (cell tensors stay uint8 views) -- what `obs` is without compact_features."""
+        obs = self.obs if slot is None else {k: v[int(slot) % self.num_slots] for k, v in self.traj.items()}
+        if not self.compact_features:
+            return dict(obs)
+        out = {k: v for k, v in obs.items() if k not in FEATURE_KEYS}
+        out.update(expand_compact_features(self.cfg, {k: v for k, v in obs.items() if k in FEATURE_KEYS}))
+        return out
 
     # -- instances --------------------------------------------------------------------------
     def load_instances(self, instances: Sequence[Instance], slot: int = 0, env_ids: Optional[Sequence[int]] = None):

@@ -73,7 +73,7 @@ def test_golden_episodes_on_gpu(name):
 
 def _oracle_rollout(cfg, B, episodes, queue_depth=2, p_bad=0.02, incremental=False, auto_reset=False, fused=False,
                     threads=0, cpu_threads=1, stats=None, max_steps=400, num_slots=1, device_instances=False, options=None,
-                    stagger=0):
+                    stagger=0, compact=False):
     """Device-sampled legal actions (plus a few corrupted ones); every observation, reward, done, info of every step
     must equal the CPU oracle's.  Covers reset_done() and the instance queue.  cpu_threads > 1: the oracle steps and
     the whole-batch tensor comparison run under OpenMP (full-size batches).  stats: filled with counts of the
@@ -81,7 +81,7 @@ def _oracle_rollout(cfg, B, episodes, queue_depth=2, p_bad=0.02, incremental=Fal
     i % L, so that from then on 1 / L of the batch ends an episode in every launch (the loop a policy runs)."""
     from oracle import oracle as orc
     env = BatchedPlacementEnv(cfg, B, queue_depth=queue_depth, run_seed=3, incremental_obs=incremental,
-                              auto_reset=auto_reset, threads_per_env=threads, num_slots=num_slots, options=options)
+                              auto_reset=auto_reset, threads_per_env=threads, num_slots=num_slots, options=options, compact_features=compact)
     if device_instances:  # fresh instances from the on-device generator; the oracle takes the host generator's records
         from pcbenv.instances import NativeInstanceStreams
         env.enable_device_instances()
@@ -137,7 +137,7 @@ def _oracle_rollout(cfg, B, episodes, queue_depth=2, p_bad=0.02, incremental=Fal
             stats["routed_terminals"] += int(dd.sum() - worst.sum())
         if auto_reset:  # observations already show the next episode of the environments that finished
             oracle_reset(dd)
-        obs = _host(o)
+        obs = _host(env.obs_f64() if compact else o)  # compact feature tensors: compared after expansion to the reference's float64
         r = r.cpu().numpy(); d = d.cpu().numpy(); inf = env.info_raw.cpu().numpy()
         assert np.array_equal(d, dd), (t, np.flatnonzero(d != dd)[:5])
         assert _same_bits(r, rr), (t, np.flatnonzero(r != rr)[:5], r[r != rr][:3], rr[r != rr][:3])
@@ -562,19 +562,25 @@ def test_trajectory_slots_every_tensor(name, mode):
     fused = mode == "fused"
     _oracle_rollout(cfg, 96, episodes=3, queue_depth=2, p_bad=0.0 if fused else 0.03, auto_reset=fused, fused=fused,
                     num_slots=5, max_steps=60)
+    if cfg.kind != KIND_SQUARE:  # the same with the compact feature tensors (int16 / int8 / uint8), expanded for the comparison
+        _oracle_rollout(cfg, 96, episodes=3, queue_depth=2, p_bad=0.0 if fused else 0.03, auto_reset=fused, fused=fused,
+                        num_slots=5, max_steps=60, compact=True)
 
 
-@pytest.mark.parametrize("name,B,T,S", [("c3", 512, 40, 41), ("c4", 256, 36, 37), ("c2", 512, 20, 7), ("c5", 64, 40, 41),
-                                        ("small_spatial", 256, 30, 31), ("c1", 64, 12, 13),
-                                        # BASELINE batches, one episode + the reset behind it, every tensor of every slot
-                                        ("c3", 4096, 17, 18), ("c4", 4096, 17, 18), ("c2", 1024, 17, 18), ("c5", 512, 33, 34)])
-def test_persistent_rollout_fills_the_trajectory(name, B, T, S):
+@pytest.mark.parametrize("name,B,T,S,compact", [("c3", 512, 40, 41, False), ("c4", 256, 36, 37, False), ("c2", 512, 20, 7, False), ("c5", 64, 40, 41, False),
+                                                ("small_spatial", 256, 30, 31, False), ("c1", 64, 12, 13, False),
+                                                # BASELINE batches, one episode + the reset behind it, every tensor of every slot
+                                                ("c3", 4096, 17, 18, False), ("c4", 4096, 17, 18, False), ("c2", 1024, 17, 18, False), ("c5", 512, 33, 34, False),
+                                                # compact feature tensors (pcbenv_bind_compact_features), expanded for the comparison
+                                                ("c3", 4096, 17, 18, True), ("c4", 4096, 17, 18, True), ("c2", 512, 20, 7, True), ("c5", 64, 40, 41, True),
+                                                ("small_spatial", 256, 30, 31, True)])
+def test_persistent_rollout_fills_the_trajectory(name, B, T, S, compact):
     """pcbenv_rollout_sampled = ONE launch for T steps with the state held in LDS: slot (1 + t) % S of every tensor, the
     recorded actions, rewards, dones and infos against the oracle stepping the same actions.  (S < T: the slots wrap.)"""
     from oracle import oracle as orc
     cfg = EnvConfig.spatial(10, 10, 3, 4, 2, 4, 2, 4, 6, 1, 2, 4, 5, 2, "both", 2, 0.5) if name == "small_spatial" else named_config(name)
     Q = 8
-    env = BatchedPlacementEnv(cfg, B, queue_depth=Q, run_seed=11, auto_reset=True, num_slots=S)
+    env = BatchedPlacementEnv(cfg, B, queue_depth=Q, run_seed=11, auto_reset=True, num_slots=S, compact_features=compact)
     packed = env.generate_instances(verify=4) if cfg.kind != KIND_SQUARE else None
     ob = orc.OracleBatch(cfg, B)
     cursor = np.zeros(B, np.int64)
@@ -595,7 +601,13 @@ def test_persistent_rollout_fills_the_trajectory(name, B, T, S):
     oracle_reset(np.ones(B, np.uint8))
     env.select_slot(1)
     acts = env.rollout_steps(0, T).cpu().numpy()
-    traj = {k: v.cpu().numpy() for k, v in env.traj.items()}
+    if compact:
+        from pcbenv.batched_env import FEATURE_KEYS, expand_compact_features
+        assert all(env.traj[k].dtype in (torch.int16, torch.int8, torch.uint8) for k in env.traj if k in FEATURE_KEYS)
+        wide = expand_compact_features(cfg, {k: v for k, v in env.traj.items() if k in FEATURE_KEYS})
+        traj = {k: (wide[k] if k in wide else v).cpu().numpy() for k, v in env.traj.items()}
+    else:
+        traj = {k: v.cpu().numpy() for k, v in env.traj.items()}
     rew, done, info = env.traj_reward.cpu().numpy(), env.traj_done.cpu().numpy(), env.traj_info.cpu().numpy()
     single = BatchedPlacementEnv(cfg, B, queue_depth=Q, run_seed=11, auto_reset=True)  # the same draws, one launch per step
     if packed is not None:

@@ -19,7 +19,7 @@ for extra in ("c3_fresh", "c3_rollout"):
     st = sorted(glob.glob(f"{src}/prof_{extra}/*/*kernel_stats.csv"), key=os.path.getmtime)
     if st:
         shutil.copy(st[-1], f"{dst}/{extra}_kernel_stats.csv")
-for f in ("stagger.txt",):
+for f in ("stagger.txt", "trajectory_one_launch_per_step.txt", "launch_times.txt"):
     if os.path.exists(f"{src}/{f}"):
         shutil.copy(f"{src}/{f}", f"{dst}/{f}")
 for cfg in ("c2", "c3", "c4", "c5", "c3_16384", "c3_65536", "c4_16384"):

@@ -31,4 +31,8 @@ python bench.py --config c3 --reward beam --no-cpu-baseline > gpurun_out/$R/c3_b
 python bench.py --config c3 --loop explicit --no-cpu-baseline > gpurun_out/$R/c3_explicit_bench.json 2>/dev/null
 python bench.py --config c3 --incremental --no-cpu-baseline > gpurun_out/$R/c3_incremental_bench.json 2>/dev/null
 python bench.py --config c4 --incremental --no-cpu-baseline > gpurun_out/$R/c4_incremental_bench.json 2>/dev/null
-for C in c3 c4 c5; do python tools/stagger_experiment.py $C; done > gpurun_out/$R/stagger.txt 2>&1
+# lock-step vs staggered episode phases: with the terminal list's helper wavefronts (default) and without (terminal_teams = 0)
+for C in c3 c4 c5; do python tools/stagger_experiment.py $C 2>&1 | grep stagger | sed "s/^/[helpers on ] /"; python tools/stagger_experiment.py $C 0 2>&1 | grep stagger | sed "s/^/[helpers off] /"; done > gpurun_out/$R/stagger.txt 2>&1
+# the trajectory layout with one launch per step (the layout a PPO collect uses): float64 vs compact feature tensors
+for C in c3 c4; do python tools/traj_step_experiment.py $C 2>&1 | grep trajectory; done > gpurun_out/$R/trajectory_one_launch_per_step.txt 2>&1
+for C in c3 c4; do python tools/launch_times.py $C 2>&1 | grep teams; python tools/launch_times.py $C "" stagger 2>&1 | grep teams; done > gpurun_out/$R/launch_times.txt 2>&1

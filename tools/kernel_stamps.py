@@ -19,7 +19,8 @@ from pcbenv.batched_env import BatchedPlacementEnv  # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else "c3"
 reward = sys.argv[3] if len(sys.argv) > 3 else "centroid"
-opts = {"terminal_teams": int(sys.argv[4])} if len(sys.argv) > 4 else None  # 0 = plain k_step, omitted = the default
+opts = {"terminal_teams": int(sys.argv[4])} if len(sys.argv) > 4 and sys.argv[4] != "-" else None  # 0 = plain k_step, omitted / "-" = the default
+traj = len(sys.argv) > 5 and sys.argv[5] == "traj"  # trajectory layout [17, B, ...] with compact feature tensors, one launch per step
 cfg = named_config(name, reward)
 B, L = int(sys.argv[2]) if len(sys.argv) > 2 else 4096, cfg.max_num_components
 TERM = [("load", 0, 1), ("sample", 1, 2), ("update", 2, 3), ("fold+emit", 3, 4), ("reward:offsets+centroids", 4, 5),
@@ -59,17 +60,19 @@ def report(title, s, done):
 
 
 for stagger in (False, True):
-    env = BatchedPlacementEnv(cfg, B, queue_depth=2, auto_reset=True, options=opts)
+    env = BatchedPlacementEnv(cfg, B, queue_depth=2, auto_reset=True, options=opts, num_slots=17 if traj else 1, compact_features=traj)
     env.generate_instances(); env.reset()
     env._L.pcbenv_debug_stamps.argtypes = [C.c_void_p, C.c_void_p]
     acts = torch.empty((B, 3), dtype=torch.int32, device="cuda")
     idx = torch.arange(B, device="cuda")
     for t in range(2 * L):
+        env.select_slot(t + 1)
         env.rollout_step(t, out=acts)
         if stagger and t < L:
             env.reset((idx % L == t).to(torch.uint8))
     seen = set()
     for k in range(3 * L):
+        env.select_slot(k)
         env.rollout_step(100 + k, out=acts)
         torch.cuda.synchronize()
         done = env.done.cpu().numpy().astype(bool)

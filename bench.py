@@ -63,24 +63,27 @@ def algorithmic_bytes_per_env_step(cfg) -> int:
     return b
 
 
-def trajectory_bytes_per_env_step(cfg) -> int:
-    """Bytes one step writes in the trajectory layout: every tensor of the slot, whole (cells + the float64 feature
-    tensors + component_grid), plus the state tables it reads and writes once per launch (not counted per step)."""
-    from pcbenv.batched_env import obs_spec
+def trajectory_bytes_per_env_step(cfg, compact=False) -> int:
+    """Bytes one step writes in the trajectory layout: every tensor of the slot, whole (cells + the feature tensors,
+    float64 or compact, + component_grid), plus the state tables it reads and writes once per launch (not counted per step)."""
+    from pcbenv.batched_env import COMPACT_DTYPES, FEATURE_KEYS, obs_spec
     import math
     total = 0
-    for shape, dt in obs_spec(cfg).values():
-        total += math.prod(shape) * (1 if dt == torch.uint8 else 8)
+    for k, (shape, dt) in obs_spec(cfg).items():
+        if compact and k in FEATURE_KEYS:
+            dt = COMPACT_DTYPES[k]
+        total += math.prod(shape) * torch.empty((), dtype=dt).element_size()
     return total + 8 + 1 + 16  # reward, done, info
 
 
-def rollout_leg(cfg, args, B, dev_index, rank, T):
+def rollout_leg(cfg, args, B, dev_index, rank, T, compact=False):
     """The persistent rollout (pcbenv_rollout_sampled): T steps per launch, state held in LDS, every step's tensors kept
     in their own slot of [T + 1, B, ...] buffers -- the on-device counterpart of the reference's simulate() loop."""
     from pcbenv.batched_env import BatchedPlacementEnv
     S = T + 1
     env = BatchedPlacementEnv(cfg, B, device=f"cuda:{dev_index}", queue_depth=4 * T if args.instances == "device" else max(args.queue_depth, 4),
-                              run_seed=args.run_seed, first_env_index=rank * B, auto_reset=True, threads_per_env=args.threads_per_env, num_slots=S)
+                              run_seed=args.run_seed, first_env_index=rank * B, auto_reset=True, threads_per_env=args.threads_per_env, num_slots=S,
+                              compact_features=compact)
     if args.instances == "device":
         env.enable_device_instances()
     else:
@@ -102,7 +105,7 @@ def rollout_leg(cfg, args, B, dev_index, rank, T):
     dt = time.perf_counter() - t0
     per_launch = [evs[k].elapsed_time(evs[k + 1]) for k in range(launches)]
     kernel_ms = evs[0].elapsed_time(evs[launches]) / launches
-    nbytes = trajectory_bytes_per_env_step(cfg)
+    nbytes = trajectory_bytes_per_env_step(cfg, compact)
     gen_errors = env.device_instance_errors() if args.instances == "device" else None
     env.close()
     gbps = nbytes * B * T / (kernel_ms * 1e-3) / 1e9
@@ -111,8 +114,10 @@ def rollout_leg(cfg, args, B, dev_index, rank, T):
             "kernel_ms_per_launch_min_median_max": [round(min(per_launch), 4), round(float(np.median(per_launch)), 4), round(max(per_launch), 4)],
             "bytes_written_per_env_step": nbytes, "achieved_GBps": round(gbps, 1), "frac_of_8TBps": round(gbps / 8000.0, 4),
             "algorithmic_GBps": round(algorithmic_bytes_per_env_step(cfg) * B * T / (kernel_ms * 1e-3) / 1e9, 1),
+            "algorithmic_frac_of_8TBps": round(algorithmic_bytes_per_env_step(cfg) * B * T / (kernel_ms * 1e-3) / 1e9 / 8000.0, 4),
+            "feature_tensors": "compact (int16 / int8 / uint8: pcbenv_bind_compact_features)" if compact else "float64",
             "instances": args.instances, "generator_errors": gen_errors,
-            "note": "every tensor of every step kept (trajectory layout), float64 feature tensors included; this rank only"}
+            "note": "every tensor of every step kept (trajectory layout), feature tensors included; this rank only"}
 
 
 def external_actions_staggered_leg(cfg, args, B, dev_index, rank):
@@ -495,6 +500,8 @@ def main():
         if dist:
             dist.barrier()
         rollout = rollout_leg(cfg, args, B, dev_index, rank, args.rollout_steps)
+        if cfg.kind != 0:  # the same with the compact feature tensors a rollout that keeps every step would bind
+            rollout["compact_features"] = rollout_leg(cfg, args, B, dev_index, rank, args.rollout_steps, compact=True)
         if dist:
             dist.barrier()
     if rank == 0:

@@ -159,3 +159,21 @@ def test_episode_export_builds_reference_components():
         assert tuple(c.position) == (obs["all_components_feature"][c.comp_id, 2], obs["all_components_feature"][c.comp_id, 3])
         for pin in c.pins:
             assert list(feats[pin.pin_id]) == [pin.relative_x, pin.relative_y, pin.absolute_x, pin.absolute_y]
+
+
+def test_expand_compact_features_is_the_reference_arithmetic():
+    """pcbenv_compact_features -> float64: every element an exact small integer, column 4 of all_components_feature the
+    ONE division the reference does (area / grid_area, S:203-239) on the same operands."""
+    import torch
+    from pcbenv.batched_env import COMPACT_DTYPES, FEATURE_KEYS, expand_compact_features, obs_spec
+    cfg = named_config("c4")
+    spec = obs_spec(cfg)
+    comp = torch.zeros((2, 3) + spec["all_components_feature"][0], dtype=torch.int16)
+    comp[..., 0] = 5; comp[..., 1] = 3; comp[..., 2] = -1; comp[..., 3] = 17; comp[..., 4] = 15; comp[..., 5:] = -1
+    comp[0, 0, 0, 5] = 47
+    num = torch.full((2, 3) + spec["all_pins_num_feature"][0], -1, dtype=torch.int8)
+    out = expand_compact_features(cfg, {"all_components_feature": comp, "all_pins_num_feature": num})
+    assert out["all_components_feature"].dtype == torch.float64 and out["all_pins_num_feature"].dtype == torch.float64
+    assert float(out["all_components_feature"][1, 2, 3, 4]) == 15 / (64 * 64) and float(out["all_components_feature"][0, 0, 0, 5]) == 47.0
+    assert float(out["all_components_feature"][0, 0, 0, 2]) == -1.0 and bool((out["all_pins_num_feature"] == -1.0).all())
+    assert set(COMPACT_DTYPES) == set(FEATURE_KEYS)

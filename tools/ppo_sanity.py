@@ -19,7 +19,7 @@ from pcbenv.ppo import PPOConfig, PPOTrainer  # noqa: E402
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 torch.manual_seed(0)
 cfg = EnvConfig.spatial(10, 10, 9, 9, 2, 2, 2, 2, 5, 5, 3, 3, 6, 6, "centroid", 2, 0.75)
-env = BatchedPlacementEnv(cfg, 1024, queue_depth=32, auto_reset=True, num_slots=11)  # trajectory layout: no observation copies
+env = BatchedPlacementEnv(cfg, 1024, queue_depth=32, auto_reset=True, num_slots=11, compact_features=True)  # trajectory layout: no observation copies; compact feature tensors
 env.enable_device_instances()  # a fresh instance for every episode, generated on the GPU
 env.reset()
 policy = SpatialPolicy(cfg).to(env.device)

@@ -42,7 +42,7 @@ if world > 1:
 torch.manual_seed(rank)  # different on purpose: the trainer must make the ranks agree
 cfg = named_config(args.config)
 B, T = args.envs, args.rollout_steps
-env = BatchedPlacementEnv(cfg, B, device=f"cuda:{dev}", queue_depth=64, auto_reset=True, first_env_index=rank * B, num_slots=T + 1)
+env = BatchedPlacementEnv(cfg, B, device=f"cuda:{dev}", queue_depth=64, auto_reset=True, first_env_index=rank * B, num_slots=T + 1, compact_features=True)
 env.enable_device_instances()
 env.reset()
 policy = SpatialPolicy(cfg).to(env.device)

@@ -35,8 +35,13 @@ __global__ __launch_bounds__(64 * NW) void k_reset(DevParams p, const unsigned c
 // Four wavefronts per SIMD (16 one-wavefront workgroups per CU) is all a launch of up to ~4 workgroups per SIMD needs and
 // what LDS allows anyway; holding the lean build to 72 VGPRs for 7 wavefronts (spills inside the routing reward and one
 // at entry) measured 2-5 % slower at every batch size, so both builds may use up to 128.
+#ifdef PCBENV_X_ROUTED5  // experiment: the routed lean builds at five wavefronts per SIMD (96 VGPRs, 24 bytes of scratch per lane)
+#define STEP_MIN_WAVES(ROUTES, TRAJ, NW) (((ROUTES) && !(TRAJ) && (NW) == 1) ? 5 : 4)
+#else
+#define STEP_MIN_WAVES(ROUTES, TRAJ, NW) 4
+#endif
 template <int KIND, int WW, int NW, bool ROUTES, bool STREAM, bool TRAJ>
-__global__ __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(64 * NW) void k_step(DevParams p, int *__restrict__ actions, int fmt, int sampled,
+__global__ __attribute__((amdgpu_waves_per_eu(STEP_MIN_WAVES(ROUTES, TRAJ, NW), 8))) __launch_bounds__(64 * NW) void k_step(DevParams p, int *__restrict__ actions, int fmt, int sampled,
                                                u64 seed, u64 first_env, u64 step_index, int num_steps_) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (!TRAJ) p.stream_stores = STREAM;  // the launch's choice as a compile-time constant: only one store policy is compiled in

@@ -5,7 +5,7 @@ set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 R=${1:-r2}
 mkdir -p gpurun_out/$R
-LEAN="--no-cpu-baseline --no-fresh-leg --rollout-steps 0"   # the headline loop only: one kernel name in the stats
+LEAN="--no-cpu-baseline --no-fresh-leg --no-staggered-leg --rollout-steps 0"   # the headline loop only: one kernel name in the stats
 for C in c3 c4 c5 c2; do
   ST=320; [ $C = c5 ] && ST=64
   python bench.py --config $C --steps $ST > gpurun_out/$R/${C}_bench.json 2> gpurun_out/$R/${C}_bench.err

@@ -35,13 +35,8 @@ __global__ __launch_bounds__(64 * NW) void k_reset(DevParams p, const unsigned c
 // Four wavefronts per SIMD (16 one-wavefront workgroups per CU) is all a launch of up to ~4 workgroups per SIMD needs and
 // what LDS allows anyway; holding the lean build to 72 VGPRs for 7 wavefronts (spills inside the routing reward and one
 // at entry) measured 2-5 % slower at every batch size, so both builds may use up to 128.
-#ifdef PCBENV_X_ROUTED5  // experiment: the routed lean builds at five wavefronts per SIMD (96 VGPRs, 24 bytes of scratch per lane)
-#define STEP_MIN_WAVES(ROUTES, TRAJ, NW) (((ROUTES) && !(TRAJ) && (NW) == 1) ? 5 : 4)
-#else
-#define STEP_MIN_WAVES(ROUTES, TRAJ, NW) 4
-#endif
 template <int KIND, int WW, int NW, bool ROUTES, bool STREAM, bool TRAJ>
-__global__ __attribute__((amdgpu_waves_per_eu(STEP_MIN_WAVES(ROUTES, TRAJ, NW), 8))) __launch_bounds__(64 * NW) void k_step(DevParams p, int *__restrict__ actions, int fmt, int sampled,
+__global__ __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(64 * NW) void k_step(DevParams p, int *__restrict__ actions, int fmt, int sampled,
                                                u64 seed, u64 first_env, u64 step_index, int num_steps_) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (!TRAJ) p.stream_stores = STREAM;  // the launch's choice as a compile-time constant: only one store policy is compiled in
@@ -62,7 +57,6 @@ __global__ __attribute__((amdgpu_waves_per_eu(STEP_MIN_WAVES(ROUTES, TRAJ, NW), 
         // (wave-uniform values the compiler cannot see as such: kept in scalar registers, like blockIdx.x)
         e = __builtin_amdgcn_readfirstlane(p.term_list[ring * (unsigned)p.term_cap + pos]);
         role = part < REWARD_PARTS ? ROLE_REWARD : ROLE_FEATURES;
-#ifndef PCBENV_X_NO_BOOKKEEPING
     } else if (p.term_cap > 0 && e == 0 && threadIdx.x < TERM_SHARDS) {
         // list bookkeeping, by the first environment workgroup: the ring after next starts empty, and the host learns how
         // long this launch's shards are (any later launch may read it, whenever: it only sizes helper grids)
@@ -81,7 +75,6 @@ __global__ __attribute__((amdgpu_waves_per_eu(STEP_MIN_WAVES(ROUTES, TRAJ, NW), 
             for (unsigned i = 1; i < 4; i++) least = min(least, hist[(p.seq + i) & 3u]);
             __hip_atomic_store(p.term_seen, least, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
-#endif
     }
     Team<64 * NW>::template run_env<KIND, WW, ROUTES, TRAJ>(p, smem, e, threadIdx.x, actions, fmt, sampled, seed, first_env, step_index,
                                                            num_steps, role, part, pos);

@@ -488,9 +488,6 @@ static int dispatch_step(pcbenv *env, int *actions, int fmt, int sampled, u64 se
         const unsigned seen = *(volatile unsigned *)env->term_seen_host;
         const long long want = (long long)TERM_SHARDS * ((long long)seen + seen / 4 + 2);
         d.term_wgs = (int)(want < env->term_wgs ? want : env->term_wgs);
-#ifdef PCBENV_X_NO_HELPERS
-        d.term_wgs = 0;
-#endif
     }
     if (capturing) d.term_cap = 0;
     // double-buffered state blocks: read the current ones, write the others

@@ -183,6 +183,27 @@ __device__ inline void mt_init_by_array(unsigned *mt, const unsigned *key, int l
 // one element per group lane in registers (free space and id of the component at each sorted position, net
 // probabilities, counts, the pin records) and are read with cross-lane reads / permutes; LDS holds one generator
 // state and the record under construction, per group.
+#ifdef GEN_MARGIN
+// Diagnostic build of tools/gen_harness.hip only: how close any draw-dependent decision of a multinomial came to its
+// threshold.  exp / log of the device library may differ from NumPy's in the last bit, which changes a probability by
+// ~1e-16 relative; a record can only differ if a uniform variate (or a probability against 0.5) lands that close to a
+// threshold.  [0] = smallest relative distance |U - px| / px seen (double bits; positive doubles order like integers),
+// [1] = the same for |P - 0.5| / 0.5, [2] = comparisons recorded, [3 + k] = how many of them were below 10^-(6 + 2 k)
+// (k < 4), [7] = comparisons exactly on the threshold.
+__device__ unsigned long long gen_margin[8];
+__device__ inline void margin_note(double a, double thr, int which) {
+    const double rel = fabs(a - thr) / (thr > 0.0 ? thr : 1.0);
+    atomicAdd(&gen_margin[2], 1ull);
+    // exactly on the threshold: only seen for P == 0.5 from two equal integer free spaces (a / (a + a), an exact division on
+    // both sides -- nothing exp / log could move); counted apart
+    if (rel == 0.0) { atomicAdd(&gen_margin[7], 1ull); return; }
+    atomicMin(&gen_margin[which], (unsigned long long)__double_as_longlong(rel));
+    for (int k = 0; k < 4; k++) if (rel < pow(10.0, -(6.0 + 2.0 * k))) atomicAdd(&gen_margin[3 + k], 1ull);
+}
+#define MARGIN(a, thr, which) margin_note(a, thr, which)
+#else
+#define MARGIN(a, thr, which) do { } while (0)
+#endif
 #ifdef GEN_COUNT_FALLBACK
 __device__ unsigned gen_fallbacks[2];
 #endif
@@ -224,10 +245,12 @@ template <int G> struct NpStream {  // NumPy legacy RandomState pieces
         const int bound = (int)((double)n < b ? (double)n : b);
         int X = 0;
         double px = qn, U = dbl();
+        MARGIN(U, px, 0);
         while (U > px) {
             X++;
             if (X > bound) { X = 0; px = qn; U = dbl(); }
             else { U -= px; px = ((double)(n - X + 1) * p * px) / ((double)X * q); }
+            MARGIN(U, px, 0);
         }
         return X;
     }
@@ -240,12 +263,14 @@ template <int G> struct NpStream {  // NumPy legacy RandomState pieces
     // EVERY possible remainder 1..n (n <= 15: four bits each); the chain itself is then a table walk.  Whenever an
     // assumption of the fast path does not hold (block refill inside the chain, a redraw, n > 15, a bin beyond the
     // inversion algorithm's range) the chain runs one binomial after the other as numpy does.
-    __device__ int multinomial(int n, double p_l, int d, bool *ok) {
+    __device__ int multinomial(int n, double p_l, int d, bool *ok, bool p_from_exp = false) {  // p_from_exp: diagnostics only (GEN_MARGIN)
         const int gl = lane & (G - 1);
         double Sum = 1.0, sum_l = 1.0;
         for (int j = 0; j < d - 1; j++) { if (gl == j) sum_l = Sum; Sum -= grl<G>(p_l, j, lane); }
         const double P_l = p_l / sum_l;                      // random_binomial(p = P_l, n = what is left)
         const bool upper_l = !(P_l <= 0.5);                  // p > 0.5: draw the complement with q = 1 - p
+        // (only probabilities that come out of exp() can be moved by its last bit: step 9's are ratios of integers)
+        if (p_from_exp && gl < d - 1 && P_l != 0.0) MARGIN(P_l, 0.5, 1);
         const double pp_l = upper_l ? 1.0 - P_l : P_l, qq_l = 1.0 - pp_l, lg_l = log(qq_l);
         const bool bin_l = gl < d - 1, draws_l = bin_l && P_l != 0.0;   // random_binomial returns 0 without a draw for p == 0
         if (rd.pos >= 624) { mt_regenerate<G>(rd.mt, gl); rd.pos = 0; rd.base = -1; }
@@ -271,10 +296,12 @@ template <int G> struct NpStream {  // NumPy legacy RandomState pieces
                     const int bound = (int)((double)m < bb ? (double)m : bb);
                     int X = 0;
                     double px = qn, U = U0;
+                    MARGIN(U, px, 0);
                     while (U > px) {
                         X++;
                         if (X > bound) { bad_l = true; break; }
                         U -= px; px = ((double)(m - X + 1) * pp_l * px) / ((double)X * qq_l);
+                        MARGIN(U, px, 0);
                     }
                     if (bad_l) break;
                     tab_l |= (u64)(unsigned)(upper_l ? m - X : X) << (4 * m);
@@ -393,7 +420,7 @@ template <int G> __device__ inline int gen_record(const GenParams &c, const GrpL
             double q_l = pr_l * (extra_l < k ? 1.0 : 0.0);
             const double sq = np_sum_lanes<G>(q_l, nn, lane);
             q_l = q_l / sq;
-            extra_l += rs.multinomial(1, q_l, nn, &ok);
+            extra_l += rs.multinomial(1, q_l, nn, &ok, true);
             if (!ok) return PCBENV_ELIMIT;
         }
     }

@@ -21,19 +21,27 @@ int main(int argc, char **argv) {
     c.min_component_w = c.min_component_h = 2; c.max_component_w = c.max_component_h = 6;
     c.max_num_components = c.min_num_components = which == 1 ? 8 : 16;
     c.net_distribution = 9; c.pin_spread = 9; c.min_num_nets = c.max_num_nets = 8; c.max_num_pins_per_net = c.min_num_pins_per_net = 6;
+    const bool ragged = argc > 4 && atoi(argv[4]) != 0;  // min < max everywhere: the truncated multinomial over the softmax (step 7) runs
+    if (ragged) { c.min_num_components = 6; c.min_num_nets = 3; c.min_num_pins_per_net = 2; }
     c.reward_type = 1; c.reward_beam_width = 2; c.weight_wirelength = 0.5; c.weight_num_intersections = 0.5;
+#ifdef GEN_MARGIN
+    const int B = 4096, Q = 64;  // a soak: 262 144 records per run
+    { unsigned long long init[8] = {~0ull, ~0ull, 0, 0, 0, 0, 0, 0}; CK(hipMemcpyToSymbol(HIP_SYMBOL(gen_margin), init, sizeof(init))); }
+#else
     const int B = 256, Q = 4;
+#endif
     c.num_envs = B; c.queue_depth = Q;
     const long long stride = pcbenv_instance_stride(&c), istride = (stride + 15) & ~15ll;
     GenParams g; memset(&g, 0, sizeof(g));
     g.kind = c.kind; g.C = c.max_num_components; g.P = pcbenv_max_total_pins(&c); g.Q = Q; g.B = B;
     g.min_comp = c.min_num_components; g.max_comp = c.max_num_components; g.min_h = g.min_w = 2; g.max_h = g.max_w = 6;
-    g.min_nets = g.max_nets = 8; g.min_ppn = g.max_ppn = 6; g.net_distribution = 9; g.pin_spread = 9; g.instStride = istride;
+    g.min_nets = c.min_num_nets; g.max_nets = 8; g.min_ppn = c.min_num_pins_per_net; g.max_ppn = 6; g.net_distribution = 9; g.pin_spread = 9; g.instStride = istride;
     unsigned *cursor, *seeds; unsigned char *queue;
     CK(hipMalloc((void **)&g.gen, sizeof(GenState) * B)); CK(hipMalloc((void **)&g.produced, 4 * B));
     CK(hipMalloc((void **)&cursor, 4 * B)); CK(hipMalloc((void **)&seeds, 4 * B)); CK(hipMalloc((void **)&queue, (size_t)istride * B * Q));
     CK(hipMemset(cursor, 0, 4 * B)); CK(hipMemset(queue, 0xEE, (size_t)istride * B * Q));
-    std::vector<unsigned> hs(B); for (int i = 0; i < B; i++) hs[i] = 7000021u + i;
+    const unsigned seed0 = argc > 3 ? (unsigned)atoll(argv[3]) : 7000021u;
+    std::vector<unsigned> hs(B); for (int i = 0; i < B; i++) hs[i] = seed0 + i;
     CK(hipMemcpy(seeds, hs.data(), 4 * B, hipMemcpyHostToDevice));
     g.queue = queue; g.cursor_pub = cursor;
     printf("stride %lld istride %lld P %d sizeof(GenState) %zu\n", stride, istride, g.P, sizeof(GenState)); fflush(stdout);
@@ -52,6 +60,14 @@ int main(int argc, char **argv) {
     printf("fill ok (G = %d lanes per environment): %d wavefronts, %d records each environment, %.1f us on an idle GPU = %.1f us per record per group\n", G, grid, Q, ms * 1e3, ms * 1e3 / Q); fflush(stdout);
 #ifdef GEN_COUNT_FALLBACK
     { unsigned fb[2]; CK(hipMemcpyFromSymbol(fb, HIP_SYMBOL(gen_fallbacks), 8)); printf("multinomial calls %u, lane-level fallback entries %u (= %u wavefront fallbacks at 64 lanes)\n", fb[1], fb[0], fb[0] / 64); }
+#endif
+#ifdef GEN_MARGIN
+    {
+        unsigned long long m[8]; CK(hipMemcpyFromSymbol(m, HIP_SYMBOL(gen_margin), sizeof(m)));
+        double a, b; memcpy(&a, &m[0], 8); memcpy(&b, &m[1], 8);
+        printf("margins over %d records (kind %d, seeds %u..): %llu draw-dependent comparisons; closest |U - px| / px = %.3e, closest |P - 0.5| / 0.5 of the softmax-derived probabilities = %.3e; "
+               "below 1e-6: %llu, 1e-8: %llu, 1e-10: %llu, 1e-12: %llu; exactly on a threshold: %llu\n", B * Q, which, seed0, m[2], a, b, m[3], m[4], m[5], m[6], m[7]);
+    }
 #endif
 #ifdef GEN_STAMPS
     {

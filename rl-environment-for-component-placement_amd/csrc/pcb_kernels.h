@@ -56,6 +56,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(64 * NW)
         pos = k;
         // (wave-uniform values the compiler cannot see as such: kept in scalar registers, like blockIdx.x)
         e = __builtin_amdgcn_readfirstlane(p.term_list[ring * (unsigned)p.term_cap + pos]);
+        if ((unsigned)e >= (unsigned)p.B) return;  // (never in a list this library wrote; an index is checked before it addresses memory all the same)
         role = part < REWARD_PARTS ? ROLE_REWARD : ROLE_FEATURES;
     } else if (p.term_cap > 0 && e == 0 && threadIdx.x < TERM_SHARDS) {
         // list bookkeeping, by the first environment workgroup: the ring after next starts empty, and the host learns how

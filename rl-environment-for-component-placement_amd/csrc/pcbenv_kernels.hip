@@ -276,6 +276,7 @@ extern "C" int pcbenv_create(const pcbenv_config *cfg, int device, pcbenv **out)
     hipMemset(d.queue, 0, qbytes ? qbytes : 16);
     hipMemset(d.cursor_pub, 0, 4 * (size_t)d.B);
     hipMemset(d.term_cnt, 0, 4 * TERM_SHARDS * TERM_CNT_STRIDE * 4 + 16);
+    hipMemset(d.term_list, 0, 4 * (size_t)4 * PCBENV_TERM_CAP_MAX);
     hipMemset(d.term_arrive, 0, 8 * (size_t)PCBENV_TERM_CAP_MAX);
     *env->term_seen_host = 0u;
     hipDeviceSynchronize();
@@ -321,9 +322,16 @@ extern "C" int pcbenv_set_option(pcbenv *env, int32_t option, int64_t value) {
         if (value > 0 && (env->threads != 64 || !is_pin_kind(env->cfg.kind)))
             return fail(env, PCBENV_EINVAL, "reward helpers need one-wavefront environments with a routing reward");
         value = (value + TERM_SHARDS - 1) & ~(long long)(TERM_SHARDS - 1);
+        {   // The lists built so far were laid out for the old capacity: drop them (counters to zero once everything enqueued
+            // has run; no mark matches the next launch's number).  A rare call: it may synchronise.
+            DEVICE_GUARD(env);
+            HIP_TRY(env, hipDeviceSynchronize());
+            HIP_TRY(env, hipMemset(env->dp.term_cnt, 0, 4 * TERM_SHARDS * TERM_CNT_STRIDE * 4 + 16));
+            *env->term_seen_host = 0u;
+        }
         env->term_wgs = (int)value;
         env->dp.term_cap = (int)value;
-        env->seq += 2;  // the lists built so far were laid out for the old capacity: no mark matches the next launch
+        env->seq += 2;
         return PCBENV_OK;
     case PCBENV_OPT_GEN_GRID:
         if (value < 1) return fail(env, PCBENV_EINVAL, "generator grid must be at least 1");

@@ -73,7 +73,7 @@ def test_golden_episodes_on_gpu(name):
 
 def _oracle_rollout(cfg, B, episodes, queue_depth=2, p_bad=0.02, incremental=False, auto_reset=False, fused=False,
                     threads=0, cpu_threads=1, stats=None, max_steps=400, num_slots=1, device_instances=False, options=None,
-                    stagger=0, compact=False):
+                    stagger=0, compact=False, toggle_helpers=False):
     """Device-sampled legal actions (plus a few corrupted ones); every observation, reward, done, info of every step
     must equal the CPU oracle's.  Covers reset_done() and the instance queue.  cpu_threads > 1: the oracle steps and
     the whole-batch tensor comparison run under OpenMP (full-size batches).  stats: filled with counts of the
@@ -118,6 +118,8 @@ def _oracle_rollout(cfg, B, episodes, queue_depth=2, p_bad=0.02, incremental=Fal
     t = 0
     keys = list(env.obs.keys())
     while done_eps < episodes * B and t < max_steps:
+        if toggle_helpers and t % 3 == 0:  # the terminal list's capacity changes under way (lists laid out for the old one are dropped)
+            env.set_option("terminal_teams", (0, 16, 64, 48)[(t // 3) % 4])
         if num_slots > 1:  # trajectory layout: step t lands in slot (t + 1) % num_slots, slot 0 took the reset
             env.select_slot(t + 1)
         if fused:
@@ -245,6 +247,30 @@ def test_terminal_teams_with_staggered_episodes(name, B, teams, fused):
     # trajectory layout
     _oracle_rollout(cfg, min(B, 128), episodes=2, queue_depth=2, p_bad=0.01, auto_reset=True, cpu_threads=16, max_steps=3 * L, options=opts, stagger=L,
                     num_slots=5)
+
+
+def test_terminal_list_capacity_changes_under_way_and_option_errors():
+    """pcbenv_set_option(PCBENV_OPT_TERMINAL_TEAMS) between steps -- off, small, larger -- with staggered episodes: results
+    unchanged (the list is a scheduling hint); and what the option call refuses."""
+    from pcbenv import _lib
+    cfg = named_config("c3")
+    _oracle_rollout(cfg, 512, episodes=3, queue_depth=3, p_bad=0.01, auto_reset=True, cpu_threads=16, max_steps=4 * cfg.max_num_components,
+                    stagger=cfg.max_num_components, toggle_helpers=True)
+    env = BatchedPlacementEnv(cfg, 8, queue_depth=1)
+    for name, value in (("terminal_teams", -1), ("terminal_teams", 5000), ("stream_threshold_bytes", -5), ("gen_grid", 0), ("gen_lanes", 48)):
+        with pytest.raises(ValueError):
+            env.set_option(name, value)
+    assert env._L.pcbenv_set_option(env._h, 99, 1) == _lib.PCBENV_EINVAL
+    env.close()
+    big = BatchedPlacementEnv(named_config("c5"), 8, queue_depth=1)   # four wavefronts per environment: no helper teams there
+    with pytest.raises(ValueError):
+        big.set_option("terminal_teams", 16)
+    big.set_option("terminal_teams", 0)
+    big.close()
+    rect = BatchedPlacementEnv(named_config("c2"), 8, queue_depth=1)  # no routing reward to share
+    with pytest.raises(ValueError):
+        rect.set_option("terminal_teams", 16)
+    rect.close()
 
 
 @pytest.mark.parametrize("threads", [64, 256])

@@ -59,22 +59,29 @@ __global__ __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(64 * NW)
         if ((unsigned)e >= (unsigned)p.B) return;  // (never in a list this library wrote; an index is checked before it addresses memory all the same)
         role = part < REWARD_PARTS ? ROLE_REWARD : ROLE_FEATURES;
     } else if (p.term_cap > 0 && e == 0 && threadIdx.x < TERM_SHARDS) {
-        // list bookkeeping, by the first environment workgroup: the ring after next starts empty, and the host learns how
-        // long this launch's shards are (any later launch may read it, whenever: it only sizes helper grids)
-        store_agent(p.term_cnt + ((((p.seq + 2u) & 3u) * TERM_SHARDS + threadIdx.x) * TERM_CNT_STRIDE), 0u);
+        // List bookkeeping, by the first environment workgroup: the ring after next starts empty, and the host learns how
+        // long the lists are (any later launch may read it, whenever: it only sizes helper grids).  Loads first, stores
+        // last: on gfx9 a wavefront's loads and stores retire through one in-order counter, so a load issued behind a
+        // store waits for that store's acknowledgement -- microseconds while the chip is saturated with stores, and this
+        // wavefront has a whole transition to do afterwards (0.3 us per launch on the lock-step loop).
+        unsigned *hist = p.term_cnt + 4u * TERM_SHARDS * TERM_CNT_STRIDE;  // behind the counters: four launches' figures, then the one the host was last told
         unsigned longest = load_agent(p.term_cnt + (((p.seq & 3u) * TERM_SHARDS + threadIdx.x) * TERM_CNT_STRIDE));
+        const unsigned h1 = hist[(p.seq + 1u) & 3u], h2 = hist[(p.seq + 2u) & 3u], h3 = hist[(p.seq + 3u) & 3u], told = hist[4];
         for (int o = TERM_SHARDS / 2; o > 0; o >>= 1) longest = max(longest, (unsigned)__shfl_xor((int)longest, o, TERM_SHARDS));
         // ... the SHORTEST of the last four launches' longest shards: with episodes in lock-step the list is full once per
         // episode and empty otherwise -- sized on that one launch, the launches that follow would each start ~2 000 idle
         // helper workgroups (+ 4 % on the lock-step loop) -- while staggered phases give steady lengths, which the minimum
         // tracks as well.  (Kept per launch on the device: the host reads whenever it enqueues, many times per launch or
         // once in many.)
+        const unsigned least = min(min(longest, h1), min(h2, h3));
+        store_agent(p.term_cnt + ((((p.seq + 2u) & 3u) * TERM_SHARDS + threadIdx.x) * TERM_CNT_STRIDE), 0u);
         if (threadIdx.x == 0) {
-            unsigned *hist = p.term_cnt + 4u * TERM_SHARDS * TERM_CNT_STRIDE;  // four words behind the counters
             hist[p.seq & 3u] = longest;
-            unsigned least = longest;
-            for (unsigned i = 1; i < 4; i++) least = min(least, hist[(p.seq + i) & 3u]);
-            __hip_atomic_store(p.term_seen, least, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            // (a store to host memory: only when the figure has grown, or shrunk by more than an eighth + 2)
+            if (least > told || least + (told >> 3) + 2u < told) {
+                hist[4] = least;
+                __hip_atomic_store(p.term_seen, least, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     }
     Team<64 * NW>::template run_env<KIND, WW, ROUTES, TRAJ>(p, smem, e, threadIdx.x, actions, fmt, sampled, seed, first_env, step_index,

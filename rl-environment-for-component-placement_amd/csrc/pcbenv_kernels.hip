@@ -259,7 +259,7 @@ extern "C" int pcbenv_create(const pcbenv_config *cfg, int device, pcbenv **out)
     if (hipMalloc((void **)&env->state_buf[0], sbytes) != hipSuccess || hipMalloc((void **)&env->state_buf[1], sbytes) != hipSuccess ||
         hipMalloc((void **)&d.queue, qbytes ? qbytes : 16) != hipSuccess ||
         hipMalloc((void **)&d.cursor_pub, 4 * (size_t)d.B) != hipSuccess ||
-        hipMalloc((void **)&d.term_list, 4 * (size_t)4 * PCBENV_TERM_CAP_MAX) != hipSuccess || hipMalloc((void **)&d.term_cnt, 4 * TERM_SHARDS * TERM_CNT_STRIDE * 4 + 16) != hipSuccess || hipMalloc((void **)&d.term_arrive, 8 * (size_t)PCBENV_TERM_CAP_MAX) != hipSuccess ||
+        hipMalloc((void **)&d.term_list, 4 * (size_t)4 * PCBENV_TERM_CAP_MAX) != hipSuccess || hipMalloc((void **)&d.term_cnt, 4 * TERM_SHARDS * TERM_CNT_STRIDE * 4 + 32) != hipSuccess || hipMalloc((void **)&d.term_arrive, 8 * (size_t)PCBENV_TERM_CAP_MAX) != hipSuccess ||
         hipHostMalloc((void **)&env->term_seen_host, 64, hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void **)&d.term_seen, env->term_seen_host, 0) != hipSuccess) {
         int r = fail(0, PCBENV_EHIP, "hipMalloc failed");
@@ -275,7 +275,7 @@ extern "C" int pcbenv_create(const pcbenv_config *cfg, int device, pcbenv **out)
     d.state = d.state_out = env->state_buf[0];
     hipMemset(d.queue, 0, qbytes ? qbytes : 16);
     hipMemset(d.cursor_pub, 0, 4 * (size_t)d.B);
-    hipMemset(d.term_cnt, 0, 4 * TERM_SHARDS * TERM_CNT_STRIDE * 4 + 16);
+    hipMemset(d.term_cnt, 0, 4 * TERM_SHARDS * TERM_CNT_STRIDE * 4 + 32);
     hipMemset(d.term_list, 0, 4 * (size_t)4 * PCBENV_TERM_CAP_MAX);
     hipMemset(d.term_arrive, 0, 8 * (size_t)PCBENV_TERM_CAP_MAX);
     *env->term_seen_host = 0u;
@@ -326,7 +326,7 @@ extern "C" int pcbenv_set_option(pcbenv *env, int32_t option, int64_t value) {
             // has run; no mark matches the next launch's number).  A rare call: it may synchronise.
             DEVICE_GUARD(env);
             HIP_TRY(env, hipDeviceSynchronize());
-            HIP_TRY(env, hipMemset(env->dp.term_cnt, 0, 4 * TERM_SHARDS * TERM_CNT_STRIDE * 4 + 16));
+            HIP_TRY(env, hipMemset(env->dp.term_cnt, 0, 4 * TERM_SHARDS * TERM_CNT_STRIDE * 4 + 32));
             *env->term_seen_host = 0u;
         }
         env->term_wgs = (int)value;

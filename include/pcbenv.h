@@ -175,7 +175,7 @@ enum pcbenv_option {
                                               end their episode get helper wavefronts in that launch (two that share the routing
                                               reward, one that writes the feature half of the reset), so that a batch whose
                                               episodes end at different times steps as fast as one in lock-step; default
-                                              num_envs / 8 for the pin kinds with one wavefront per environment, 0 = off */
+                                              num_envs / 8 for the pin kinds, 0 = off */
     PCBENV_OPT_GEN_GRID = 3,               /* workgroups of a refill launch of the on-device generator (default 2 048) */
     PCBENV_OPT_GEN_LANES = 4               /* lanes per environment of the generator kernel: 0 = narrowest the
                                               configuration allows, 32 / 64 force a wider group; before enabling it */

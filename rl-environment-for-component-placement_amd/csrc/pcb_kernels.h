@@ -24,7 +24,7 @@ __global__ __launch_bounds__(64 * NW) void k_reset(DevParams p, const unsigned c
 }
 
 // The step kernel, one team of NW wavefronts per workgroup (Team<>::run_env has the story).  A launch with helpers
-// (p.term_wgs > 0: one transition per launch, one-wavefront teams, pin kinds) starts with term_wgs * term_hpe
+// (p.term_wgs > 0: one transition per launch, pin kinds) starts with term_wgs * term_hpe
 // helpers -- workgroup k * term_hpe + part serves entry k of the terminal list, entries being numbered idx *
 // TERM_SHARDS + shard so that the occupied ones (the low idx of every shard) come first; unused ones look at their
 // shard's counter and leave -- followed by the B environments' own teams.  The helpers come FIRST so that they hold a
@@ -43,7 +43,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(64 * NW)
     const int num_steps = TRAJ ? num_steps_ : 1;
     // above the generator's wavefronts (priority 0) when both share a SIMD: the step kernel is the latency-critical one
     __builtin_amdgcn_s_setprio(3);
-    constexpr bool HELPERS = NW == 1 && (KIND == PCBENV_PIN || KIND == PCBENV_SPATIAL);
+    constexpr bool HELPERS = KIND == PCBENV_PIN || KIND == PCBENV_SPATIAL;
     const int nh = HELPERS ? p.term_wgs * p.term_hpe : 0;  // helper workgroups at the head of the grid
     int e = (int)blockIdx.x - nh, role = ROLE_ENV, part = 0;
     unsigned pos = 0u;

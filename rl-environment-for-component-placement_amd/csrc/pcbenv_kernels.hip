@@ -247,7 +247,7 @@ extern "C" int pcbenv_create(const pcbenv_config *cfg, int device, pcbenv **out)
     // 16-component episode (PCBENV_OPT_TERMINAL_TEAMS changes or disables it).
     env->seq = 0;
     env->term_wgs = 0;
-    if (env->threads == 64 && is_pin_kind(c.kind)) {
+    if (is_pin_kind(c.kind)) {
         int wgs = (c.num_envs / 8 + (int)TERM_SHARDS - 1) & ~((int)TERM_SHARDS - 1);
         env->term_wgs = wgs < (int)TERM_SHARDS ? (int)TERM_SHARDS : wgs > PCBENV_TERM_CAP_MAX ? PCBENV_TERM_CAP_MAX : wgs;
     }
@@ -319,8 +319,8 @@ extern "C" int pcbenv_set_option(pcbenv *env, int32_t option, int64_t value) {
         return PCBENV_OK;
     case PCBENV_OPT_TERMINAL_TEAMS:
         if (value < 0 || value > PCBENV_TERM_CAP_MAX) return fail(env, PCBENV_EINVAL, "terminal-list entries must be in [0, 4096]");
-        if (value > 0 && (env->threads != 64 || !is_pin_kind(env->cfg.kind)))
-            return fail(env, PCBENV_EINVAL, "reward helpers need one-wavefront environments with a routing reward");
+        if (value > 0 && !is_pin_kind(env->cfg.kind))
+            return fail(env, PCBENV_EINVAL, "reward helpers need an environment kind with a routing reward");
         value = (value + TERM_SHARDS - 1) & ~(long long)(TERM_SHARDS - 1);
         {   // The lists built so far were laid out for the old capacity: drop them (counters to zero once everything enqueued
             // has run; no mark matches the next launch's number).  A rare call: it may synchronise.

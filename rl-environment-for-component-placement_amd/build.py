@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
-UNITS = (["pcb_kind_square.hip", "pcb_kind_rect.hip"] + [f"pcb_kind_{k}_{p}.hip" for p in (2, 3, 0) for k in ("spatial", "pin")]  # slowest first
+UNITS = (["pcb_kind_square.hip", "pcb_kind_rect.hip"] + [f"pcb_kind_{k}_{p}.hip" for p in (2, 3, 0, 1) for k in ("spatial", "pin")]  # slowest first
          + ["pcbenv_kernels.hip", "instance_gen.cpp"])
 SRC = [os.path.join(CSRC, u) for u in UNITS]
 DEPS = SRC + [os.path.join(REPO, "include", "pcbenv.h")] + sorted(

@@ -35,12 +35,22 @@ __global__ __launch_bounds__(64 * NW) void k_reset(DevParams p, const unsigned c
 // Four wavefronts per SIMD (16 one-wavefront workgroups per CU) is all a launch of up to ~4 workgroups per SIMD needs and
 // what LDS allows anyway; holding the lean build to 72 VGPRs for 7 wavefronts (spills inside the routing reward and one
 // at entry) measured 2-5 % slower at every batch size, so both builds may use up to 128.
-template <int KIND, int WW, int NW, bool ROUTES, bool STREAM, bool TRAJ>
+// BUILD: what is a compile-time fact of the launch.  STEP_BUILD_INPLACE / _INPLACE_STREAM: the in-place layout, one
+// transition, write-through / streaming stores (the lean build: no step loop, no whole-tensor feature emission);
+// STEP_BUILD_SLOT: the trajectory layout, one transition per launch (what a PPO collect runs: whole-tensor emission, no
+// loop -- 80 VGPRs and 140 spilled scalars against the rollout build's 125 and 800, c4 68 instead of 80 us per step);
+// STEP_BUILD_ROLLOUT: the trajectory layout and num_steps transitions per launch (the persistent rollout).
+#define STEP_BUILD_INPLACE 0
+#define STEP_BUILD_INPLACE_STREAM 1
+#define STEP_BUILD_SLOT 2
+#define STEP_BUILD_ROLLOUT 3
+template <int KIND, int WW, int NW, bool ROUTES, int BUILD>
 __global__ __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(64 * NW) void k_step(DevParams p, int *__restrict__ actions, int fmt, int sampled,
                                                u64 seed, u64 first_env, u64 step_index, int num_steps_) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if (!TRAJ) p.stream_stores = STREAM;  // the launch's choice as a compile-time constant: only one store policy is compiled in
-    const int num_steps = TRAJ ? num_steps_ : 1;
+    constexpr bool TRAJ = BUILD == STEP_BUILD_SLOT || BUILD == STEP_BUILD_ROLLOUT;
+    if (!TRAJ) p.stream_stores = BUILD == STEP_BUILD_INPLACE_STREAM;  // the launch's choice as a compile-time constant: only one store policy is compiled in
+    const int num_steps = BUILD == STEP_BUILD_ROLLOUT ? num_steps_ : 1;
     // above the generator's wavefronts (priority 0) when both share a SIMD: the step kernel is the latency-critical one
     __builtin_amdgcn_s_setprio(3);
     constexpr bool HELPERS = KIND == PCBENV_PIN || KIND == PCBENV_SPATIAL;

@@ -169,8 +169,9 @@ static __device__ __forceinline__ void transition(const DevParams &p, Lds &l, in
 
 // One team's share of a step launch: state block -> LDS, num_steps transitions of environment e, state block back.
 // TRAJ = false is the lean build for the in-place layout and one transition per launch (num_slots == 1 and num_steps == 1
-// are then compile-time facts: no step loop, no whole-tensor feature emission -- 84 instead of 112-121 VGPRs); TRAJ =
-// true serves the trajectory layout and the persistent rollout.  num_steps == 1: one transition with the given (or,
+// are then compile-time facts: no step loop, no whole-tensor feature emission -- 84 instead of 112-125 VGPRs); TRAJ =
+// true serves the trajectory layout -- with num_steps a compile-time 1 in k_step's STEP_BUILD_SLOT (no loop either: 80
+// VGPRs) -- and the persistent rollout.  num_steps == 1: one transition with the given (or,
 // `sampled`, a uniformly drawn legal) action.  num_steps > 1 (sampled only) is the persistent rollout: num_steps
 // transitions of environment e in ONE launch (step t draws with step_index + t, exactly what k_sample or a single-step
 // launch would draw).  The state block stays in LDS for the whole rollout -- no reload / write-back, no launch latency

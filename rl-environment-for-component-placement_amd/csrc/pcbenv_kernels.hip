@@ -475,7 +475,7 @@ static int dispatch_step(pcbenv *env, int *actions, int fmt, int sampled, u64 se
     DevParams &d = a.d;
     a.actions = actions; a.fmt = fmt; a.sampled = sampled; a.seed = seed; a.first_env = first_env; a.step_index = step_index;
     a.num_steps = num_steps; a.threads = env->threads; a.stream = s;
-    // lean build (in-place layout, one transition, store policy compiled in) or the trajectory / rollout build
+    // in-place build (one transition, store policy compiled in) or the trajectory layout's: one transition into a slot / the rollout loop
     a.traj = d.num_slots > 1 || num_steps > 1;
     // The trajectory layout cycles through num_slots slots: the store policy is chosen on the bytes of all of them (a slot is
     // next written num_slots steps later; one launch per step into a [17, B, ...] trajectory measured + 14 % at c3, + 3 % at

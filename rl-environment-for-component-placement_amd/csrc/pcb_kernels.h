@@ -3,11 +3,24 @@
 #pragma once
 #include "pcb_team.h"
 
+// Workgroups go to the eight XCDs round-robin (blockIdx.x % 8).  Environment of workgroup `block` (the environments'
+// workgroups follow `head` others): XCD * B/8 + turn, so that each XCD -- each L2 -- owns a contiguous eighth of every
+// tensor.  Rows smaller than a cache line (reward, done, info, actions, the compact features) and the ends of the
+// others then share their lines with neighbours under the SAME L2, which merges them into whole-line writes; with
+// environment = blockIdx.x every such line went to memory in up to eight pieces (c3: 19.65 -> 19.1 us per launch, c4
+// 44.8 -> 44.3, same-box A/B in profiles/r3/ab_xcd_contiguous_environments.txt).  Any bijection serves: the
+// environments are independent, and nothing else depends on which workgroup runs which.
+__device__ inline int xcd_contiguous_env(int block, int head, int B) {
+    if (B & 7) return block - head;
+    const int x = block & 7, first = head + ((x - head) & 7);  // first: the XCD's first environment workgroup
+    return x * (B >> 3) + (block - first) / 8;
+}
+
 template <int KIND, int WW, int NW>
 __global__ __launch_bounds__(64 * NW) void k_reset(DevParams p, const unsigned char *__restrict__ mask) {
     typedef Team<64 * NW> T;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int e = blockIdx.x, lane = threadIdx.x;
+    const int e = xcd_contiguous_env((int)blockIdx.x, 0, p.B), lane = threadIdx.x;
     if (mask && !mask[e]) return;
     T::load_state(smem, p, e, lane);  // cursor / episode survive; the old pins tell which feature rows to clear
     typename T::Lds l = T::carve(smem, p);
@@ -56,6 +69,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(64 * NW)
     constexpr bool HELPERS = KIND == PCBENV_PIN || KIND == PCBENV_SPATIAL;
     const int nh = HELPERS ? p.term_wgs * p.term_hpe : 0;  // helper workgroups at the head of the grid
     int e = (int)blockIdx.x - nh, role = ROLE_ENV, part = 0;
+    if (e >= 0) e = xcd_contiguous_env((int)blockIdx.x, nh, p.B);
     unsigned pos = 0u;
     if (HELPERS && e < 0) {  // a reward helper
         const unsigned hb = blockIdx.x, hpe = (unsigned)p.term_hpe, k = hb / hpe;  // hpe = REWARD_PARTS (+ 1: the feature helper)

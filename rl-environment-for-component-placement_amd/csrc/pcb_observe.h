@@ -225,13 +225,22 @@ static __device__ inline void build_pin_tables(const DevParams &p, Lds &l, int l
 }
 // S:1677-1697 draw_components from the tables above: byte (cell, ch) = ch == 0 ? component exists : net ch-1 has a
 // pin on the cell; each byte written once.
+// chunk [bb, bb + 16) of a `total`-byte tensor row (total a multiple of 4): whole, or -- the last one -- the dwords inside the row
+static __device__ inline void store16_or_tail(const ObsDst &d, unsigned char *dst, int bb, int total, uint4 v, bool stream) {
+    if (bb + 16 <= total) { STORE16_dyn(d, (unsigned)bb, v, stream); return; }
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+    #pragma unroll
+    for (int j = 0; j < 4; j++) if (bb + 4 * j < total) *(unsigned *)(dst + bb + 4 * j) = w[j];
+}
 static __device__ inline void emit_component_grid_to(const DevParams &p, Lds &l, unsigned char *cg, int lane) {
     const PinTables t = pin_tables(p, l);
     const int nc = l.hdr->ncomp;
     const int cells = p.mh * p.mw, cgsz = cells * p.K, total = p.C * cgsz;
-    if ((total & 15) == 0 && (((uintptr_t)cg) & 15) == 0) {
+    // 16-byte chunks at 4-byte alignment (c4: 2 916 bytes per environment, every row a multiple of 4 only -- gfx9 under HSA
+    // runs in unaligned-access mode, where a 16-byte access needs dword alignment), the last chunk's dwords one by one
+    if ((total & 3) == 0 && (((uintptr_t)cg) & 3) == 0) {
         const ObsDst d = obs_dst(cg, total);
-        for (int c16 = lane; c16 < total / 16; c16 += NT) {
+        for (int c16 = lane; c16 < (total + 15) / 16; c16 += NT) {
             const int bb = c16 * 16;
             int cell = bb / p.K, ch = bb - cell * p.K;
             u64 field = ((u64)t.netmask[cell] << 1) | (u64)(cell / cells < nc);  // bit ch = byte value of channel ch
@@ -242,7 +251,7 @@ static __device__ inline void emit_component_grid_to(const DevParams &p, Lds &l,
                 if (k < 8) lo |= bit << (8 * k); else hi |= bit << (8 * (k - 8));
                 if (++ch == p.K) { ch = 0; cell++; field = cell < p.C * cells ? (((u64)t.netmask[cell] << 1) | (u64)(cell / cells < nc)) : 0ull; }
             }
-            STORE16_dyn(d, (unsigned)bb, make_uint4((unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)), p.stream_stores);
+            store16_or_tail(d, cg, bb, total, make_uint4((unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)), p.stream_stores);
         }
     } else {
         for (int i = lane; i < total; i += NT) {
@@ -307,10 +316,10 @@ static __device__ inline void feat_cache_emit(const DevParams &p, Lds &l, int e,
     if (p.buf.component_grid) {
         const int total = p.C * p.mh * p.mw * p.K;
         unsigned char *cg = p.buf.component_grid + (size_t)row * total;
-        const uint4 *src = (const uint4 *)(base + p.featCacheCg);
-        if ((total & 15) == 0 && (((uintptr_t)cg) & 15) == 0) {
+        const uint4 *src = (const uint4 *)(base + p.featCacheCg);  // (16-byte aligned, and padded to whole chunks)
+        if ((total & 3) == 0 && (((uintptr_t)cg) & 3) == 0) {
             const ObsDst d = obs_dst(cg, total);
-            for (int c16 = lane; c16 < total / 16; c16 += NT) STORE16_dyn(d, (unsigned)c16 * 16u, src[c16], p.stream_stores);
+            for (int c16 = lane; c16 < (total + 15) / 16; c16 += NT) store16_or_tail(d, cg, c16 * 16, total, src[c16], p.stream_stores);
         } else {
             for (int i = lane; i < total; i += NT) cg[i] = base[p.featCacheCg + i];
         }
@@ -356,7 +365,7 @@ template <int KIND> static __device__ inline void emit_features_compact(const De
     }
     if (KIND == PCBENV_RECT && p.cbuf.component_mask) {
         unsigned char *cm = p.cbuf.component_mask + (size_t)row * p.C;
-        for (int c = lane; c < p.C; c += NT) cm[c] = c < nc ? 1 : 0;
+        for (int c = lane; c < p.C; c += NT) cm[c] = (unsigned char)(c < nc ? 1 : 0);
     }
     if (KIND == PCBENV_PIN || KIND == PCBENV_SPATIAL) {
         // one 32-bit word per pin row of all_pins_num_feature, one byte / 16-bit word per row of all_pins_cat_feature
@@ -367,7 +376,7 @@ template <int KIND> static __device__ inline void emit_features_compact(const De
         if (KIND == PCBENV_SPATIAL) {  // row = global pin id: rows 0..np-1 belong to pins, the others are constant
             for (int r = np + lane; r < p.pinRows; r += NT) {
                 if (fn) fn[r] = 0u;
-                if (fc) ((unsigned short *)fc)[r] = r == p.pinRows - 1 ? 0xFFFFu : 0u;  // (net, component) of a row as one 16-bit word
+                if (fc) ((unsigned short *)fc)[r] = (unsigned short)(r == p.pinRows - 1 ? 0xFFFFu : 0u);  // (net, component) of a row as one 16-bit word
             }
             for (int q = lane; q < np; q += NT) {
                 const PinRec pr = l.pins[q];
@@ -389,7 +398,7 @@ template <int KIND> static __device__ inline void emit_features_compact(const De
             for (int r = lane; r < p.pinRows; r += NT) {
                 if ((rowbits[r >> 6] >> (r & 63)) & 1ull) continue;
                 if (fn) fn[r] = 0u;
-                if (fc) fc[r] = 0;
+                if (fc) fc[r] = (signed char)0;
             }
             for (int q = lane; q < np; q += NT) {
                 const PinRec pr = l.pins[q];

@@ -123,20 +123,34 @@ static __device__ __forceinline__ void transition(const DevParams &p, Lds &l, in
             const bool inc = (p.flags & PCBENV_FLAG_INCREMENTAL_OBS) != 0;
             const int r0 = inc ? x : 0, r1 = inc ? min(x + ph, H) : H;
             const bool skip_emit = auto_reset && KIND != PCBENV_SQUARE && l.hdr->cur < 0;
-            if (TRAJ && full && !skip_emit) {  // every float64 tensor of the fresh slot, and the episode-constant component_grid
-                if (KIND == PCBENV_SPATIAL && feat_cache_valid(p, l, e)) {  // ... copied from the episode's cache where there is one
+            // Trajectory layout: every feature tensor of the fresh slot, and the episode-constant component_grid -- copied
+            // from the episode's cache where there is one.  They go LAST where nothing they touch in LDS is needed by the
+            // cell tensors' emission: their reads (the cache: HBM reads on a chip saturated with writes, ~2 us a round
+            // trip, five of them) and small stores then overlap the drain of the 56 KB the wavefront has just issued,
+            // instead of holding those back at a time when every wavefront of the launch is doing the same (c4:
+            // 71.5 -> 64-67 us per step, profiles/r3/ab_trajectory_slot_build.txt).
+            const bool slot_features = TRAJ && full && !skip_emit;
+            const bool from_cache = slot_features && KIND == PCBENV_SPATIAL && feat_cache_valid(p, l, e);
+            const bool late = slot_features && (KIND == PCBENV_SPATIAL ? from_cache : KIND == PCBENV_PIN);
+            auto emit_slot_features = [&]() {
+                if (from_cache) {
+                    STAMP(5);  // (stamps 5-7 are the reward's in a terminal transition: a non-terminal one has them free)
                     emit_features_full<KIND>(p, l, row, lane, true);
+                    STAMP(6);
                     feat_cache_emit(p, l, e, row, lane);
+                    STAMP(7);
                 } else {
                     if (KIND == PCBENV_SPATIAL) build_pin_tables(p, l, lane);
                     emit_features_full<KIND>(p, l, row, lane);
                     if (KIND == PCBENV_SPATIAL) { emit_component_grid(p, l, row, lane); lds_sync(); }
                 }
-            }
+            };
+            if (slot_features && !late) emit_slot_features();
             const bool any = mask_and_emit<KIND, WW>(p, l, row, lane, !skip_emit, r0, r1);
             STAMP(23);
             if (KIND == PCBENV_SPATIAL && !skip_emit) emit_pin_grid<WW>(p, l, row, lane, r0, r1);
             STAMP(4);
+            if (late) emit_slot_features();
             done = KIND == PCBENV_SQUARE ? !any : (l.hdr->cur < 0 || !any);  // S:1856-1869
         }  // (a reward helper: the last component has just been placed -- that is what being listed is conditional on)
     } else if (!valid && TRAJ && full && !auto_reset && obs) {  // a fresh slot: the unchanged observation has to be written out all the same

@@ -30,6 +30,8 @@ TERM = [("load", 0, 1), ("sample", 1, 2), ("update", 2, 3), ("fold+emit", 3, 4),
         ("store state", 20, 11)]
 NONT = [("load", 0, 1), ("sample", 1, 2), ("update", 2, 3), ("fold+emit grid/mask", 3, 23), ("emit pin_grid", 23, 4), ("rest", 4, 10), ("presample", 10, 20),
         ("store state", 20, 11)]
+if traj and name in ("c4", "c5"):  # spatial, trajectory layout: the feature part of the slot in detail
+    NONT[3:4] = [("cache tag", 3, 5), ("compact feature tensors", 5, 6), ("copy from the episode's cache", 6, 7), ("fold+emit grid/mask", 7, 23)]
 
 
 def report(title, s, done):
@@ -40,10 +42,11 @@ def report(title, s, done):
     print(f"  wave starts p50/max {q(a, .5):.2f}/{q(a, 1):.2f} us, ends p1/p50/p99/max {q(b, .01):.2f}/{q(b, .5):.2f}/"
           f"{q(b, .99):.2f}/{q(b, 1):.2f} us, median wave {np.median(b - a) * 10e-3:.2f} us, shader clock ~{clk:.0f} MHz")
     e = np.arange(len(a))
-    by_xcd = [float(np.median(b[e % 8 == x] - a.min())) * 10e-3 for x in range(8)]
-    print("  median end by e % 8 (XCD): " + " ".join(f"{t:.1f}" for t in by_xcd) + " us; by (e // 8) % 4: " +
-          " ".join(f"{float(np.median(b[(e // 8) % 4 == x] - a.min())) * 10e-3:.1f}" for x in range(4)) +
-          "; by e // (B/8): " + " ".join(f"{float(np.median(b[e // (len(a) // 8) == x] - a.min())) * 10e-3:.1f}" for x in range(8)))
+    # environment e runs on XCD e // (B/8), as the (e % (B/8))-th workgroup of that XCD (k_step: xcd_contiguous_env)
+    n8 = len(a) // 8
+    by_xcd = [float(np.median(b[e // n8 == x] - a.min())) * 10e-3 for x in range(8)]
+    print("  median end by XCD (e // (B/8)): " + " ".join(f"{t:.1f}" for t in by_xcd) + " us; by dispatch order within the XCD, in eighths: " +
+          " ".join(f"{float(np.median(b[(e % n8) // max(n8 // 8, 1) == x] - a.min())) * 10e-3:.1f}" for x in range(8)))
     for label, rows, table in (("terminal", s[done], TERM), ("non-terminal", s[~done], NONT)):
         if len(rows):
             print(f"  {label}: total {int(np.median(rows[:, 11] - rows[:, 0]))} cycles")

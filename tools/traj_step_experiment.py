@@ -10,7 +10,7 @@ from pcbenv.batched_env import BatchedPlacementEnv
 name = sys.argv[1] if len(sys.argv) > 1 else "c4"
 cfg = named_config(name)
 B = int(sys.argv[2]) if len(sys.argv) > 2 else {"c2": 1024, "c3": 4096, "c4": 4096, "c5": 8192}[name]
-T = 16
+T = int(os.environ.get('TRAJ_T', '16'))  # slots - 1
 threads = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 quick = len(sys.argv) > 4
 for compact in ((True,) if quick else (False, True)):
@@ -33,5 +33,5 @@ for compact in ((True,) if quick else (False, True)):
                 env.select_slot((t + 1) % (T + 1)); env.rollout_step(1000 + t, out=acts)
             torch.cuda.synchronize(); dt = time.perf_counter() - t0
             print(f"{name} x{B}{f' ({threads} threads per environment)' if threads else ''} trajectory layout, one launch per step: features {'compact' if compact else 'float64'}, instances {'fresh (device)' if fresh else 'replayed'}, "
-                  f"stores {'streaming' if stream == 0 else 'by size'}: {B * K / dt / 1e6:.1f} M env-steps/s, {dt / K * 1e6:.1f} us/step", flush=True)
+                  f"stores {'streaming' if stream == 0 else 'by size'}, {T + 1} slots: {B * K / dt / 1e6:.1f} M env-steps/s, {dt / K * 1e6:.1f} us/step", flush=True)
             env.close()

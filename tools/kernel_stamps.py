@@ -30,8 +30,8 @@ TERM = [("load", 0, 1), ("sample", 1, 2), ("update", 2, 3), ("fold+emit", 3, 4),
         ("store state", 20, 11)]
 NONT = [("load", 0, 1), ("sample", 1, 2), ("update", 2, 3), ("fold+emit grid/mask", 3, 23), ("emit pin_grid", 23, 4), ("rest", 4, 10), ("presample", 10, 20),
         ("store state", 20, 11)]
-if traj and name in ("c4", "c5"):  # spatial, trajectory layout: the feature part of the slot in detail
-    NONT[3:4] = [("cache tag", 3, 5), ("compact feature tensors", 5, 6), ("copy from the episode's cache", 6, 7), ("fold+emit grid/mask", 7, 23)]
+if traj and name in ("c4", "c5"):  # spatial, trajectory layout: the feature part of the slot (it follows the cell tensors) in detail
+    NONT[3:6] = [("cache tag + fold+emit grid/mask", 3, 23), ("emit pin_grid", 23, 4), ("compact feature tensors", 5, 6), ("copy from the episode's cache", 6, 7), ("rest", 7, 10)]
 
 
 def report(title, s, done):

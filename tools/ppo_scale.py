@@ -58,21 +58,24 @@ tr.timing = {"collect_s": 0.0, "update_s": 0.0, "env_steps": 0}
 tr.train(args.iters)
 tm = tr.timing
 # env-only: the same number of steps with uniformly sampled legal actions, same trajectory layout
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-for it in range(args.iters):
+# (one untimed pass first -- the update has just had the GPU to itself -- then at least twenty: 48 launches were a 4 ms sample)
+env_iters = max(args.iters, 20)
+for it in range(-1, env_iters):
+    if it == 0:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
     for t in range(T):
         env.select_slot((t + 1) % (T + 1))
-        env.rollout_step(10_000 + it * T + t)
+        env.rollout_step(10_000 + (it + 1) * T + t)
 torch.cuda.synchronize()
-env_only = B * T * args.iters / (time.perf_counter() - t0)
+env_only = B * T * env_iters / (time.perf_counter() - t0)
 params = sum(p.numel() for p in policy.parameters())
 out = {"config": args.config, "envs_per_gpu": B, "n_gpus": world, "rollout_steps": T, "iterations": args.iters,
        "policy_parameters": params, "epochs": args.epochs, "minibatches": args.minibatches,
        "train_env_steps_per_sec_per_gpu": round(tm["env_steps"] / (tm["collect_s"] + tm["update_s"]), 1),
        "rollout_env_steps_per_sec_per_gpu": round(tm["env_steps"] / tm["collect_s"], 1),
        "collect_s_per_iter": round(tm["collect_s"] / args.iters, 4), "update_s_per_iter": round(tm["update_s"] / args.iters, 4),
-       "env_only_env_steps_per_sec_per_gpu": round(env_only, 1),
+       "env_only_env_steps_per_sec_per_gpu": round(env_only, 1), "env_only_launches": env_iters * T,
        "mean_return_per_iter": tr.returns[-args.iters:], "generator_errors": env.device_instance_errors(),
        "collectives": ("rccl all-gather of advantages + gradient all-reduce + BatchNorm statistics all-reduce" if world > 1 else "none (1 rank)"),
        "observation_copies_per_step": 0}

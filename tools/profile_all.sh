@@ -1,11 +1,12 @@
 #!/bin/bash
 # Round-end evidence on the GPU box: bench JSON, rocprofv3 kernel stats and PMC traffic (separate passes) per config.
-#   tools/profile_all.sh r2 [quick]
+#   tools/profile_all.sh r2 [quick | rest]   (quick: the per-config part only; rest: everything after it -- two calls fit gpurun's limit)
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 R=${1:-r2}
 mkdir -p gpurun_out/$R
 LEAN="--no-cpu-baseline --no-fresh-leg --no-staggered-leg --rollout-steps 0"   # the headline loop only: one kernel name in the stats
+if [ "$2" != rest ]; then
 for C in c3 c4 c5 c2; do
   ST=320; [ $C = c5 ] && ST=64
   python bench.py --config $C --steps $ST > gpurun_out/$R/${C}_bench.json 2> gpurun_out/$R/${C}_bench.err
@@ -22,6 +23,7 @@ for CB in c3:16384 c3:65536 c4:16384; do
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/$R/pmcf_${C}_$B -- python3 bench.py --config $C --envs $B --steps 32 --warmup 16 --repeats 1 --no-kernel-events $LEAN > gpurun_out/$R/pmcf_${C}_$B.log 2>&1
   echo "== $C x $B"; tail -n1 gpurun_out/$R/${C}_${B}_bench.json | cut -c1-200
 done
+fi
 [ "$2" = quick ] && exit 0
 # the other loops: fresh on-device instances and the persistent rollout (kernel names k_step<..., TRAJ> and k_gen_fill)
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/prof_c3_fresh -- python3 bench.py --config c3 --instances device --no-cpu-baseline --rollout-steps 0 --repeats 1 > gpurun_out/$R/prof_c3_fresh.log 2>&1

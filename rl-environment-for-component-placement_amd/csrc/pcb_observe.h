@@ -46,7 +46,7 @@ static __device__ inline void store_state(const unsigned char *smem, const DevPa
     lds_sync();
     uint4 *dst = (uint4 *)(p.state_out + (size_t)e * p.stateStride);
     const uint4 *src = (const uint4 *)smem;
-    // plain write-back stores: environment e runs on XCD e % 8 in every launch, so its state block is an L2 hit next step
+    // plain write-back stores: environment e runs on the same XCD in every launch (xcd_contiguous_env), so its state block is an L2 hit next step
     for (int i = lane; i < (int)(p.stateStride / 16); i += NT) dst[i] = src[i];
 }
 

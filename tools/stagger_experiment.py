@@ -1,16 +1,16 @@
 """Lock-step vs staggered episode phases (1/C of the environments terminal in every launch): one launch per step -- with
 the fused sampler and with EXTERNAL actions (a policy between the steps: pcbenv_sample_actions + pcbenv_step here) --
 and the persistent rollout (16 steps per launch), where wavefronts drift apart anyway.
-python tools/stagger_experiment.py c3 [terminal_teams]   (terminal_teams: 0 = plain k_step, omitted = the default)"""
+python tools/stagger_experiment.py c3 [terminal_teams [reward_type]]   (terminal_teams: 0 = plain k_step, omitted or "-" = the default)"""
 import sys, time, os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rl-environment-for-component-placement_amd"))
 import torch
 from pcbenv import named_config
 from pcbenv.batched_env import BatchedPlacementEnv
 name = sys.argv[1] if len(sys.argv) > 1 else "c3"
-cfg = named_config(name); B = {"c2": 4096, "c3": 4096, "c4": 4096, "c5": 8192}[name]
+cfg = named_config(name, sys.argv[3]) if len(sys.argv) > 3 else named_config(name); B = {"c2": 4096, "c3": 4096, "c4": 4096, "c5": 8192}[name]
 L = cfg.max_num_components
-opts = {"terminal_teams": int(sys.argv[2])} if len(sys.argv) > 2 else None
+opts = {"terminal_teams": int(sys.argv[2])} if len(sys.argv) > 2 and sys.argv[2] != "-" else None
 for stagger in (False, True):
     env = BatchedPlacementEnv(cfg, B, queue_depth=2, auto_reset=True, options=opts)
     env.generate_instances(); env.reset()

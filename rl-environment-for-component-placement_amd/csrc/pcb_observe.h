@@ -109,8 +109,11 @@ static __device__ inline bool mask_and_emit(const DevParams &p, Lds &l, int row,
     return any;
 }
 
-// S:1663-1675 draw_pins: class map (0 empty, 1 occupied without pin, n+2 pin of net n) -> one-hot[:, :, 1:];
-// rows [r0, r1) of the (H, W, K) tensor (a step only changes the rows of the placed rectangle).
+// S:1663-1675 draw_pins: class map (CLS_EMPTY, 1 occupied without pin, n+2 pin of net n) -> one-hot[:, :, 1:];
+// rows [r0, r1) of the (H, W, K) tensor (a step only changes the rows of the placed rectangle).  An empty cell's class
+// is 0x80, not 0: "byte of the cell's 1 = first byte of the cell + class - 1" then lands far outside any chunk without a
+// test of its own.
+#define CLS_EMPTY 0x80u
 template <int WW> static __device__ inline void emit_pin_grid(const DevParams &p, Lds &l, int row, int lane, int r0, int r1) {
     if (!p.buf.pin_grid) return;
     const int W = p.W, HW = p.H * W, K = p.K;
@@ -121,12 +124,14 @@ template <int WW> static __device__ inline void emit_pin_grid(const DevParams &p
         const int sh = (W & (W - 1)) == 0 ? __ffs(W) - 1 : -1;
         for (int ch = c0 / 16 + lane; ch < c1 / 16; ch += NT) {
             const int cell = ch * 16, r = sh >= 0 ? cell >> sh : cell / W, c = cell - r * W;
-            *(uint4 *)(l.cls + cell) = expand16((unsigned)(l.occ[r * WW + (c >> 6)] >> (c & 63)) & 0xFFFFu);
+            uint4 v = expand16((unsigned)(l.occ[r * WW + (c >> 6)] >> (c & 63)) & 0xFFFFu);  // bytes 0 / 1 -> CLS_EMPTY / 1
+            v.x |= (v.x ^ 0x01010101u) << 7; v.y |= (v.y ^ 0x01010101u) << 7; v.z |= (v.z ^ 0x01010101u) << 7; v.w |= (v.w ^ 0x01010101u) << 7;
+            *(uint4 *)(l.cls + cell) = v;
         }
     } else {
         for (int i = c0 + lane; i < c1; i += NT) {
             int r = i / W, c = i - r * W;
-            l.cls[i] = (unsigned char)((l.occ[r * WW + (c >> 6)] >> (c & 63)) & 1ull);
+            l.cls[i] = (unsigned char)(((l.occ[r * WW + (c >> 6)] >> (c & 63)) & 1ull) ? 1u : CLS_EMPTY);
         }
     }
     lds_sync();
@@ -139,38 +144,41 @@ template <int WW> static __device__ inline void emit_pin_grid(const DevParams &p
         const ObsDst d = obs_dst(dst, b1);
         // every cell owns K consecutive bytes with at most one 1 (at class-1): visit the <= 16/K + 2 cells a
         // 16-byte chunk overlaps and drop their 1-bytes into two 64-bit halves
-        const unsigned kinv = 0xFFFFFFFFu / (unsigned)K + 1u;  // floor(b / K) == umulhi(b, kinv) for b < 2^32 / K
-        auto chunks = [&](auto stream_tag) {  // store policy fixed per call, not per store
+        // first cell of a lane's first chunk and the chunk's offset inside it by one division; from chunk to chunk (16 * NT
+        // bytes on) by an add and a conditional carry (two quarter-rate multiplies per chunk before)
+        const int first = ((int)(b0 / 16) + lane) * 16, dcell = 16 * NT / K, drem = 16 * NT - dcell * K;
+        auto chunks = [&](auto stream_tag, auto cells_tag) {  // store policy and cells per chunk fixed per call, not per store
+            constexpr int NC = decltype(cells_tag)::value;
+            int cell0 = first / K, rem = first - cell0 * K;  // chunk byte bb = cell0 * K + rem, 0 <= rem < K
             for (int c = (int)(b0 / 16) + lane; c < (int)(b1 / 16); c += NT) {
                 const int bb = c * 16;
-                int cell = (int)__umulhi((unsigned)bb, kinv);
-                if (cell * K > bb) cell--;  // (never taken at these sizes; keeps the division exact regardless)
-                u64 lo = 0, hi = 0;
-                if (K >= 5) {  // a chunk overlaps at most ceil((15 + K) / K) <= 4 cells: their classes are read together (one LDS round trip per store, not one per cell)
-                    unsigned cl[4];
+                int cell = cell0;
+                const int rem_now = rem;
+                cell0 += dcell; rem += drem;
+                if (rem >= K) { rem -= K; cell0++; }
+                unsigned ones = 0u;  // bit b = byte b of the chunk is 1
+                if (K >= 5) {  // a chunk overlaps at most ceil((15 + K) / K) cells -- 3 from K = 8 on (c4 / c5: K = 9), 4 below: their classes are read together (one LDS round trip per store, not one per cell)
+                    unsigned cl[NC];
                     #pragma unroll
-                    for (int j = 0; j < 4; j++) cl[j] = cell + j < c1 ? (unsigned)l.cls[cell + j] : 0u;
-                    const int rel = cell * K - bb - 1;  // byte of cell j's 1 inside the chunk: rel + j * K + class
+                    for (int j = 0; j < NC; j++) cl[j] = cell + j < c1 ? (unsigned)l.cls[cell + j] : CLS_EMPTY;
+                    const int rel = -rem_now - 1;  // = cell * K - bb - 1; byte of cell j's 1 inside the chunk: rel + j * K + class
                     #pragma unroll
-                    for (int j = 0; j < 4; j++) {  // branch-free: one 64-bit shift and two selects per cell
+                    for (int j = 0; j < NC; j++) {  // branch-free: an add, a compare, a shift, a select and an or per cell
                         const unsigned off = (unsigned)(rel + j * K + (int)cl[j]);
-                        const u64 m = (u64)(cl[j] != 0 && off < 16u) << ((off & 7u) * 8u);
-                        lo |= (off & 8u) ? 0ull : m;
-                        hi |= (off & 8u) ? m : 0ull;
+                        ones |= off < 16u ? 1u << off : 0u;
                     }
                 } else {
-                    for (int base = cell * K; base < bb + 16 && cell < c1; base += K, cell++) {
-                        const unsigned cl = l.cls[cell];
-                        const int off = base + (int)cl - 1 - bb;  // byte of this cell's 1 inside the chunk
-                        if (cl != 0 && off >= 0 && off < 16) {
-                            if (off < 8) lo |= 1ull << (8 * off); else hi |= 1ull << (8 * (off - 8));
-                        }
+                    for (int base = bb - rem_now; base < bb + 16 && cell < c1; base += K, cell++) {
+                        const unsigned off = (unsigned)(base + (int)l.cls[cell] - 1 - bb);  // byte of this cell's 1 inside the chunk
+                        if (off < 16u) ones |= 1u << off;
                     }
                 }
-                STORE16<decltype(stream_tag)::value>(d, (unsigned)bb, make_uint4((unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)));
+                STORE16<decltype(stream_tag)::value>(d, (unsigned)bb, expand16(ones));
             }
         };
-        if (p.stream_stores) chunks(std::true_type{}); else chunks(std::false_type{});
+        typedef std::integral_constant<int, 3> three; typedef std::integral_constant<int, 4> four;
+        if (K >= 8) { if (p.stream_stores) chunks(std::true_type{}, three{}); else chunks(std::false_type{}, three{}); }
+        else { if (p.stream_stores) chunks(std::true_type{}, four{}); else chunks(std::false_type{}, four{}); }
     } else {
         for (long long i = b0 + lane; i < b1; i += NT) {
             int cell = (int)(i / K), ch = (int)(i - (long long)cell * K);
